@@ -1,0 +1,220 @@
+/*
+ * rtgpu.h — C ABI of the MI355X trace-loop library (librtgpu.so).
+ *
+ * The reference snapshot (Condzi/rt @ v1) has NO renderer, no plugin/FFI
+ * interface and no render entry point.  The seam this
+ * library fills is the gap in the reference frame loop between
+ * win32_message_loop() and gfx_render() (code/first.cpp:78-88).  Each entry
+ * point below therefore cites the reference convention it follows rather than
+ * a reference function it replaces.
+ *
+ * Conventions taken from the reference:
+ *   - POD structs of f32/u32 only, designated-initialiser friendly, no STL,
+ *     no virtuals (code/first.hpp:16-37, scripts/build_internal.bat:4).
+ *   - Vectors are 3 consecutive f32 (rt::Vec3, code/math/vec.hxx:18-28);
+ *     accumulation pixels are 4 consecutive f32 (rt::Vec4, vec.hxx:30-48).
+ *   - Screen space is y-up, origin bottom-left (code/math/mat.cxx:104-129):
+ *     pixel (x, y) lives at index y*width + x and row 0 is the BOTTOM row.
+ *   - 8-bit colours are packed 0xRRGGBBAA (code/gfx/gfx.hpp:4-6,
+ *     run_tree/data/shaders/shaders.hlsl:18-25).
+ *   - The C layer never exits; it returns non-zero and keeps a message
+ *     (rtgpu_last_error).  The C++ facade (rt_amd/host/rt.hpp) turns that into
+ *     the reference's fatal errf() convention (code/first.cpp:27-43).
+ *   - Caller owns host memory passed in, the library copies; device memory is
+ *     owned by the context (arena ownership rule, code/base/memory.cxx:23-50).
+ *
+ * All functions are thread-compatible per context (the reference is single
+ * threaded: code/gfx/gfx.cpp:36); calls on one context must not overlap.
+ */
+#ifndef RTGPU_H
+#define RTGPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTGPU_ABI_VERSION 1u
+
+/* ---- scene description (host side, caller-owned) ------------------------ */
+
+enum {
+  RTGPU_MAT_LAMBERTIAN = 0u, /* param unused                                  */
+  RTGPU_MAT_METAL      = 1u, /* param = fuzz in [0,1]                         */
+  RTGPU_MAT_DIELECTRIC = 2u  /* param = index of refraction                   */
+};
+
+/* Material semantics follow the literature the reference cites
+ * (notes/materials.md:3-5 -> "Ray Tracing in One Weekend"): a tagged POD, not a
+ * class hierarchy.  32 bytes. */
+typedef struct rtgpu_material {
+  float    albedo[3];
+  float    param;
+  uint32_t type;
+  uint32_t _pad[3];
+} rtgpu_material;
+
+typedef struct rtgpu_sphere {     /* 20 bytes */
+  float    center[3];
+  float    radius;
+  uint32_t material;
+} rtgpu_sphere;
+
+typedef struct rtgpu_triangle {   /* 40 bytes */
+  float    v0[3], v1[3], v2[3];
+  uint32_t material;
+} rtgpu_triangle;
+
+/* Primitive ids reported by the renderer: sphere i -> i,
+ * triangle j -> n_spheres + j, miss -> RTGPU_NO_HIT. */
+#define RTGPU_NO_HIT 0xFFFFFFFFu
+
+typedef struct rtgpu_scene_desc {
+  const rtgpu_sphere   *spheres;   uint64_t n_spheres;
+  const rtgpu_triangle *triangles; uint64_t n_triangles;
+  const rtgpu_material *materials; uint64_t n_materials;
+} rtgpu_scene_desc;
+
+/* ---- camera -------------------------------------------------------------- */
+
+/* Thin-lens camera already reduced to the vectors the per-ray code consumes.
+ * Fill it with rtgpu_camera_look_at() so every caller (C++, Python, oracle
+ * tests) gets the same f32 values.  80 bytes. */
+typedef struct rtgpu_camera {
+  float origin[3];
+  float lower_left[3];
+  float horizontal[3];
+  float vertical[3];
+  float u[3];          /* lens basis, unit */
+  float v[3];
+  float lens_radius;   /* 0 => pinhole, no lens RNG draws */
+  float _pad;
+} rtgpu_camera;
+
+/* ---- render settings ----------------------------------------------------- */
+
+enum {
+  RTGPU_FLAG_ACCUMULATE = 1u, /* out = in + frame (progressive), else out = frame */
+  RTGPU_FLAG_COMPACT    = 2u, /* write this rank's tiles as a compact tile list   */
+  RTGPU_FLAG_STATS      = 4u  /* run the instrumented variant (node/prim counters) */
+};
+
+typedef struct rtgpu_settings {
+  uint32_t width, height;
+  uint32_t spp;            /* samples per pixel traced by this call            */
+  uint32_t sample_offset;  /* index of the first sample (progressive frames)   */
+  uint32_t max_depth;      /* max segments per path                            */
+  uint32_t seed;
+  float    tmin;           /* self-intersection offset, e.g. 1e-3              */
+  float    sky_bottom[3];  /* miss shader: bottom*(1-t) + top*t, t=0.5(d.y+1)  */
+  float    sky_top[3];
+  uint32_t tile_size;      /* multi-GPU tile edge (pixels), power of two >= 8  */
+  uint32_t rank;           /* this context renders tiles t with t % world == rank */
+  uint32_t world_size;
+  uint32_t flags;
+} rtgpu_settings;
+
+typedef struct rtgpu_stats {
+  uint64_t paths;          /* (pixel, sample) pairs traced                     */
+  uint64_t rays;           /* segments traced (primary + every bounce)         */
+  uint64_t nodes;          /* 64-byte BVH nodes fetched      (STATS flag only) */
+  uint64_t tri_tests;      /* ray-triangle tests             (STATS flag only) */
+  uint64_t sphere_tests;   /* ray-sphere tests               (STATS flag only) */
+  uint64_t scatters;       /* material fetch + scatter evals (STATS flag only) */
+} rtgpu_stats;
+
+/* Flattened scene as it lives in HBM (and in a host mirror).  Exposed so that
+ * tests can hand the *same* buffers to the CPU oracle, and so a caller can
+ * serialise them.  Pointers are owned by the context. */
+typedef struct rtgpu_flat_scene {
+  const void    *nodes;        uint64_t n_nodes;      /* 64 B each  */
+  const void    *tris;         uint64_t n_tris;       /* 48 B each, leaf order */
+  const void    *spheres;      uint64_t n_spheres;    /* 16 B each, leaf order */
+  const uint32_t*sphere_meta;                         /* 2 u32 each: id, material */
+  const void    *materials;    uint64_t n_materials;  /* 32 B each  */
+  uint32_t       max_depth;    /* deepest leaf (root = 0)           */
+  uint32_t       _pad;
+  double         build_ms;
+} rtgpu_flat_scene;
+
+typedef struct rtgpu_ctx rtgpu_ctx;
+
+/* ---- entry points -------------------------------------------------------- */
+
+/* Follows X_init_or_panic (code/gfx/gfx.hpp:21) minus the panic: binds one
+ * context to one GPU (one process per GPU is the intended multi-GPU use). */
+int  rtgpu_create(rtgpu_ctx **out, int device_index);
+void rtgpu_destroy(rtgpu_ctx *ctx);
+const char *rtgpu_last_error(const rtgpu_ctx *ctx);  /* ctx may be NULL: last create error */
+uint32_t rtgpu_abi_version(void);
+
+/* Builds the BVH on the host, flattens scene + BVH into SoA node/primitive
+ * buffers and copies them to HBM. */
+int  rtgpu_upload_scene(rtgpu_ctx *ctx, const rtgpu_scene_desc *scene);
+int  rtgpu_get_flat_scene(const rtgpu_ctx *ctx, rtgpu_flat_scene *out);
+
+/* Host-only variant of the two calls above: build + flatten without a GPU
+ * (used by CPU-side tests and tools).  Free with rtgpu_flat_scene_free. */
+int  rtgpu_flatten_scene_host(const rtgpu_scene_desc *scene, rtgpu_flat_scene *out);
+void rtgpu_flat_scene_free(rtgpu_flat_scene *fs);
+
+/* The trace loop (rows a1, a3-a8).  Blocking.  accum_rgba: host, width*height
+ * float4 {sum r, sum g, sum b, sample count}; prim_id (optional): host,
+ * width*height u32, primary-hit primitive of sample `sample_offset`.
+ * With RTGPU_FLAG_COMPACT the outputs hold only this rank's tiles
+ * (rtgpu_compact_pixels() pixels, tile-major). */
+int  rtgpu_render(rtgpu_ctx *ctx, const rtgpu_camera *cam, const rtgpu_settings *s,
+                  float *accum_rgba, uint32_t *prim_id, rtgpu_stats *stats);
+
+/* Same, outputs in device memory of the context's GPU, launched on `stream`
+ * (a hipStream_t, NULL = default stream).  Asynchronous unless `stats` is
+ * non-NULL (then it synchronises the stream to read the counters back). */
+int  rtgpu_render_device(rtgpu_ctx *ctx, const rtgpu_camera *cam, const rtgpu_settings *s,
+                         void *d_accum_rgba, void *d_prim_id, void *stream,
+                         rtgpu_stats *stats);
+
+/* Duration of the trace kernel of the last render call on this context,
+ * measured with HIP events on the stream the kernel ran on.  Synchronises. */
+int  rtgpu_last_kernel_ms(rtgpu_ctx *ctx, float *ms);
+
+/* accum (float4 sums) -> 0xRRGGBBAA, gamma 2, like RTIOW's write_color.
+ * Packing per run_tree/data/shaders/shaders.hlsl:18-25. Device pointers. */
+int  rtgpu_resolve_rgba8_device(rtgpu_ctx *ctx, const void *d_accum_rgba, void *d_rgba8,
+                                uint64_t n_pixels, void *stream);
+int  rtgpu_resolve_rgba8(rtgpu_ctx *ctx, const float *accum_rgba, uint32_t *rgba8,
+                         uint64_t n_pixels);
+
+/* Multi-GPU helpers.  Number of pixels in the compact buffer
+ * of `rank`, and the scatter of `world_size` gathered compact buffers
+ * (concatenated, each padded to rtgpu_compact_pixels(.., rank 0) pixels) back
+ * into a width*height image.  elem_bytes is 16 (accum) or 4 (prim ids). */
+uint64_t rtgpu_compact_pixels(uint32_t width, uint32_t height, uint32_t tile_size,
+                              uint32_t rank, uint32_t world_size);
+int  rtgpu_untile_device(rtgpu_ctx *ctx, const void *d_gathered, void *d_image,
+                         uint32_t width, uint32_t height, uint32_t tile_size,
+                         uint32_t world_size, uint32_t elem_bytes, void *stream);
+
+/* Camera helper: RTIOW look-at thin-lens camera, computed in f64 and rounded
+ * once to f32 so all callers agree bit-for-bit.  Row-vector convention of
+ * code/math/mat.cxx:12-20 is not involved: the camera is stored as vectors. */
+void rtgpu_camera_look_at(rtgpu_camera *cam, const float from[3], const float at[3],
+                          const float up[3], float vfov_deg, float aspect,
+                          float aperture, float focus_dist);
+
+void rtgpu_default_settings(rtgpu_settings *s, uint32_t width, uint32_t height,
+                            uint32_t spp, uint32_t max_depth);
+
+/* Procedural scenes of SURVEY.md §8d (no assets exist offline).
+ * kind: 0 = S0 "default" (RTIOW cover + quad), 1 = S1 "mesh" (displaced
+ * icosphere, `param` = subdivision level, 8 => 1,310,720 tris),
+ * 2 = S2 "soup" (8 displaced icospheres, mixed materials, `param` = level).
+ * The arrays are malloc'ed; free with rtgpu_scene_free. */
+int  rtgpu_scene_builtin(uint32_t kind, uint32_t seed, uint32_t param,
+                         rtgpu_scene_desc *out, rtgpu_camera *cam_out, float aspect);
+void rtgpu_scene_free(rtgpu_scene_desc *scene);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTGPU_H */

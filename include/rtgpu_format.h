@@ -1,0 +1,56 @@
+/*
+ * rtgpu_format.h — byte layout of the flattened scene in HBM (SURVEY.md §8a
+ * row a2).  This is a DATA FORMAT shared by the product (rt_amd/csrc) and the
+ * CPU oracle (oracle/rt_oracle.c): both walk the same buffers, which is what
+ * makes primary-hit ids comparable bit-for-bit, ties included.  It has no
+ * counterpart in the reference (no BVH exists there).
+ *
+ * All records are arrays of 32-bit words, little endian; f32 = IEEE binary32
+ * (rt::f32, code/first.hpp:26), u32 = rt::u32 (code/first.hpp:18).
+ */
+#ifndef RTGPU_FORMAT_H
+#define RTGPU_FORMAT_H
+
+#include <stdint.h>
+
+/* BVH2 node, 64 bytes, 64-byte aligned: one node = both children's boxes, so a
+ * traversal step costs exactly one 64-byte fetch (4 x dwordx4 per lane). */
+typedef struct rtgpu_node {
+  float    lo0[3], hi0[3];   /* AABB of child 0 */
+  float    lo1[3], hi1[3];   /* AABB of child 1 */
+  uint32_t child0, child1;   /* child references, see below */
+  uint32_t _pad[2];
+} rtgpu_node;
+
+/* Child reference (also the traversal-stack entry):
+ *   bit 31 = 0 : inner node, bits 0..30 = node index
+ *   bit 31 = 1 : leaf; bit 30 = 1 sphere / 0 triangle;
+ *                bits 27..29 = count-1 (1..8 primitives, one type per leaf);
+ *                bits 0..26  = first index into the leaf-ordered array
+ *   0xFFFFFFFF : empty child (its box is inverted and never hit)            */
+#define RTGPU_REF_LEAF    0x80000000u
+#define RTGPU_REF_SPHERE  0x40000000u
+#define RTGPU_REF_EMPTY   0xFFFFFFFFu
+#define RTGPU_REF_COUNT(r) ((((r) >> 27) & 7u) + 1u)
+#define RTGPU_REF_FIRST(r) ((r) & 0x07FFFFFFu)
+#define RTGPU_MAX_PRIMS_PER_TYPE 0x07FFFFF8u
+
+/* Triangle, 48 bytes, leaf order: v0, e1 = v1-v0, e2 = v2-v0 (f32 subtraction
+ * done once on the host); the spare w lanes carry id and material. */
+typedef struct rtgpu_tri {
+  float v0[3]; uint32_t prim_id;
+  float e1[3]; uint32_t material;
+  float e2[3]; uint32_t _pad;
+} rtgpu_tri;
+
+/* Sphere, 16 bytes, leaf order; {prim_id, material} live in a parallel array
+ * (8 bytes) fetched only for the closest hit. */
+typedef struct rtgpu_sph {
+  float c[3]; float r;
+} rtgpu_sph;
+
+/* Traversal stack bound: the builder never produces a tree deeper than this
+ * (root = depth 0), and both the kernel and the oracle size stacks from it. */
+#define RTGPU_MAX_TREE_DEPTH 62u
+
+#endif

@@ -1,0 +1,652 @@
+/*
+ * rt_oracle.c — CPU oracle for the per-pixel trace loop.  TEST INFRASTRUCTURE:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this.  The product (librtgpu.so) never links, loads or calls it.
+ *
+ * PARITY UNPINNED BY THE REFERENCE.  The reference snapshot (Condzi/rt @ v1)
+ * contains no ray tracer, no RNG, no scene and no test or golden vector for
+ * this path.  This file is therefore the written
+ * specification of the trace loop, not a restatement of reference code, for
+ * everything except the vector arithmetic, which IS present in the reference
+ * and is followed operation for operation:
+ *
+ *   v3_dot        code/math/vec.cxx:94-97   multiply, then x + y + z left to right
+ *   v3_len        code/math/vec.cxx:52-54   sqrt(dot(v, v))
+ *   v3_normalize  code/math/vec.cxx:66-69   v *= 1/len(v)  (reciprocal, then multiply)
+ *   v3 + - *      code/math/vec.cxx:174-211 component-wise, scalar on the right
+ *   rgba8 packing run_tree/data/shaders/shaders.hlsl:18-25, code/gfx/gfx.hpp:4-6
+ *   y-up rows     code/math/mat.cxx:104-129
+ *
+ * Those rows are pinned against the reference's own code compiled from
+ * /root/reference (oracle/_ref, see oracle/Makefile) and against the vectors
+ * committed in tests/golden/ref_math.json.
+ *
+ * Material semantics follow the literature the reference cites as its study
+ * material (notes/materials.md:3-5): P. Shirley, "Ray Tracing in One Weekend"
+ * — lambertian, metal with fuzz, dielectric with Schlick, sky gradient.
+ *
+ * ARITHMETIC CONTRACT (both this file and the HIP kernel):
+ *   IEEE-754 binary32, round to nearest even; no contraction (compile with
+ *   -ffp-contract=off) — the ONLY fused operations are the explicit fmaf()
+ *   calls of the slab test; division and sqrt correctly rounded; fminf/fmaxf
+ *   only ever see non-NaN operands; no transcendental functions.
+ *   The random stream is a counter-based integer hash, so a path's result does
+ *   not depend on scheduling, tile order or GPU count.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "rtgpu.h"        /* POD structs of the C ABI (data only) */
+#include "rtgpu_format.h" /* flattened scene layout (data only)   */
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define RTO_API __attribute__((visibility("default")))
+
+/* ---- RNG (row a7) ---------------------------------------------------------- */
+
+/* PCG-RXS-M-XS 32-bit permutation (M. O'Neill, "PCG", 2014): a bijection on u32. */
+static inline uint32_t pcg(uint32_t v) {
+  uint32_t s = v * 747796405u + 2891336453u;
+  uint32_t w = ((s >> ((s >> 28) + 4u)) ^ s) * 277803737u;
+  return (w >> 22) ^ w;
+}
+
+/* One key per (pixel, sample): bijective in `sample` for a fixed pixel, so two
+ * samples of one pixel never share a stream. */
+static inline uint32_t path_key(uint32_t pixel, uint32_t sample, uint32_t seed) {
+  return pcg(sample ^ pcg(pixel ^ pcg(seed)));
+}
+
+typedef struct { uint32_t key, ctr; } rng_t;
+
+static inline float u01(rng_t *r) {
+  uint32_t h = pcg(r->key + r->ctr * 0x9E3779B9u);
+  r->ctr++;
+  return (float)(h >> 8) * 0x1p-24f;
+}
+
+RTO_API uint32_t rto_pcg(uint32_t v) { return pcg(v); }
+RTO_API uint32_t rto_path_key(uint32_t pixel, uint32_t sample, uint32_t seed) {
+  return path_key(pixel, sample, seed);
+}
+RTO_API float rto_u01(uint32_t key, uint32_t ctr) {
+  rng_t r = {key, ctr};
+  return u01(&r);
+}
+
+/* ---- vector arithmetic (row a9) ---------------------------------------------- */
+
+typedef struct { float x, y, z; } v3;
+
+static inline v3 v3_add(v3 a, v3 b) { v3 r = {a.x + b.x, a.y + b.y, a.z + b.z}; return r; }
+static inline v3 v3_sub(v3 a, v3 b) { v3 r = {a.x - b.x, a.y - b.y, a.z - b.z}; return r; }
+static inline v3 v3_mul(v3 a, v3 b) { v3 r = {a.x * b.x, a.y * b.y, a.z * b.z}; return r; }
+static inline v3 v3_scale(v3 a, float s) { v3 r = {a.x * s, a.y * s, a.z * s}; return r; }
+static inline float v3_dot(v3 a, v3 b) {
+  a = v3_mul(a, b);
+  return a.x + a.y + a.z;
+}
+static inline float v3_len(v3 a) { return sqrtf(v3_dot(a, a)); }
+static inline v3 v3_normalize(v3 a) { return v3_scale(a, 1.0f / v3_len(a)); }
+/* not in the reference (code/math/vec.hxx has no cross): mul, mul, sub per lane */
+static inline v3 v3_cross(v3 a, v3 b) {
+  v3 r = {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+  return r;
+}
+static inline v3 v3_neg(v3 a) { v3 r = {-a.x, -a.y, -a.z}; return r; }
+static inline v3 v3_from(const float *p) { v3 r = {p[0], p[1], p[2]}; return r; }
+
+RTO_API float rto_dot3(const float *a, const float *b) { return v3_dot(v3_from(a), v3_from(b)); }
+RTO_API float rto_len3(const float *a) { return v3_len(v3_from(a)); }
+RTO_API void rto_normalize3(const float *a, float *out) {
+  v3 r = v3_normalize(v3_from(a));
+  out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+RTO_API void rto_cross3(const float *a, const float *b, float *out) {
+  v3 r = v3_cross(v3_from(a), v3_from(b));
+  out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+/* rt::transformed_point, row-vector convention (code/math/mat.cxx:12-20) */
+RTO_API void rto_transform_point4(const float *p, const float *m /*4x4 row major*/, float *out) {
+  for (int c = 0; c < 4; c++)
+    out[c] = p[0] * m[0 * 4 + c] + p[1] * m[1 * 4 + c] + p[2] * m[2 * 4 + c] + p[3] * m[3 * 4 + c];
+}
+
+/* ---- intersection primitives (rows a3-a5) ------------------------------------ */
+
+typedef struct {
+  v3 o, d;        /* d is unit length (normalised at generation and after scatter) */
+  v3 inv;         /* 1/d with |d| clamped away from 0                              */
+  v3 noi;         /* -(o * inv), the addend of the fma-form slab test               */
+} ray_t;
+
+static inline float clamp_dir(float d) {
+  return fabsf(d) < 1e-30f ? copysignf(1e-30f, d) : d;
+}
+
+static inline void ray_prepare(ray_t *r) {
+  r->inv.x = 1.0f / clamp_dir(r->d.x);
+  r->inv.y = 1.0f / clamp_dir(r->d.y);
+  r->inv.z = 1.0f / clamp_dir(r->d.z);
+  r->noi.x = -(r->o.x * r->inv.x);
+  r->noi.y = -(r->o.y * r->inv.y);
+  r->noi.z = -(r->o.z * r->inv.z);
+}
+
+/* Slab test.  Returns hit and the entry distance used for near-first ordering. */
+static inline int slab(const ray_t *r, const float *lo, const float *hi, float tmin, float tbest,
+                       float *tnear_out) {
+  float t0x = fmaf(lo[0], r->inv.x, r->noi.x), t1x = fmaf(hi[0], r->inv.x, r->noi.x);
+  float t0y = fmaf(lo[1], r->inv.y, r->noi.y), t1y = fmaf(hi[1], r->inv.y, r->noi.y);
+  float t0z = fmaf(lo[2], r->inv.z, r->noi.z), t1z = fmaf(hi[2], r->inv.z, r->noi.z);
+  float tnear = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), tmin));
+  float tfar  = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tbest));
+  *tnear_out = tnear;
+  return tnear <= tfar;
+}
+
+/* Ray-sphere, half-b form with a = 1 (unit direction); nearest root in (tmin, tbest). */
+static inline int hit_sphere(const ray_t *r, const rtgpu_sph *s, float tmin, float tbest, float *t_out) {
+  v3 c = {s->c[0], s->c[1], s->c[2]};
+  v3 oc = v3_sub(r->o, c);
+  float hb = v3_dot(oc, r->d);
+  float cc = v3_dot(oc, oc) - s->r * s->r;
+  float disc = hb * hb - cc;
+  if (disc < 0.0f) return 0;
+  float sq = sqrtf(disc);
+  float t = -hb - sq;
+  if (!(t > tmin && t < tbest)) {
+    t = -hb + sq;
+    if (!(t > tmin && t < tbest)) return 0;
+  }
+  *t_out = t;
+  return 1;
+}
+
+/* Moller-Trumbore, two-sided. */
+static inline int hit_tri(const ray_t *r, const rtgpu_tri *tr, float tmin, float tbest, float *t_out) {
+  v3 v0 = v3_from(tr->v0), e1 = v3_from(tr->e1), e2 = v3_from(tr->e2);
+  v3 pvec = v3_cross(r->d, e2);
+  float det = v3_dot(e1, pvec);
+  if (fabsf(det) < 1e-30f) return 0;
+  float inv_det = 1.0f / det;
+  v3 tvec = v3_sub(r->o, v0);
+  float u = v3_dot(tvec, pvec) * inv_det;
+  if (u < 0.0f || u > 1.0f) return 0;
+  v3 qvec = v3_cross(tvec, e1);
+  float v = v3_dot(r->d, qvec) * inv_det;
+  if (v < 0.0f || u + v > 1.0f) return 0;
+  float t = v3_dot(e2, qvec) * inv_det;
+  if (!(t > tmin && t < tbest)) return 0;
+  *t_out = t;
+  return 1;
+}
+
+RTO_API int rto_kat_slab(const float *o, const float *d, const float *lo, const float *hi,
+                         float tmin, float tbest, float *tnear) {
+  ray_t r;
+  r.o = v3_from(o);
+  r.d = v3_from(d);
+  ray_prepare(&r);
+  return slab(&r, lo, hi, tmin, tbest, tnear);
+}
+RTO_API int rto_kat_sphere(const float *o, const float *d, const float *sph4, float tmin,
+                           float tbest, float *t) {
+  ray_t r;
+  rtgpu_sph s = {{sph4[0], sph4[1], sph4[2]}, sph4[3]};
+  r.o = v3_from(o);
+  r.d = v3_from(d);
+  *t = 0.0f;
+  return hit_sphere(&r, &s, tmin, tbest, t);
+}
+RTO_API int rto_kat_tri(const float *o, const float *d, const float *v0, const float *v1,
+                        const float *v2, float tmin, float tbest, float *t) {
+  ray_t r;
+  rtgpu_tri tr;
+  memset(&tr, 0, sizeof(tr));
+  for (int k = 0; k < 3; k++) {
+    tr.v0[k] = v0[k];
+    tr.e1[k] = v1[k] - v0[k];
+    tr.e2[k] = v2[k] - v0[k];
+  }
+  r.o = v3_from(o);
+  r.d = v3_from(d);
+  *t = 0.0f;
+  return hit_tri(&r, &tr, tmin, tbest, t);
+}
+
+/* ---- scene access ------------------------------------------------------------- */
+
+typedef struct {
+  const rtgpu_node *nodes;
+  const rtgpu_tri *tris;
+  const rtgpu_sph *sphs;
+  const uint32_t *sph_meta;
+  const rtgpu_material *mats;
+  uint64_t n_nodes, n_tris, n_sphs, n_mats;
+} scene_t;
+
+typedef struct {
+  int hit;
+  int is_sphere;
+  uint32_t slot;  /* index into the leaf-ordered array of its type */
+  float t;
+} hit_t;
+
+typedef struct {
+  uint64_t paths, rays, nodes, tri_tests, sphere_tests, scatters;
+} counters_t;
+
+static inline void leaf_intersect(const scene_t *sc, const ray_t *r, uint32_t ref, float tmin,
+                                  hit_t *best, counters_t *cn) {
+  uint32_t first = RTGPU_REF_FIRST(ref), count = RTGPU_REF_COUNT(ref);
+  if (ref & RTGPU_REF_SPHERE) {
+    for (uint32_t i = first; i < first + count; i++) {
+      float t;
+      cn->sphere_tests++;
+      if (hit_sphere(r, &sc->sphs[i], tmin, best->t, &t)) {
+        best->hit = 1; best->is_sphere = 1; best->slot = i; best->t = t;
+      }
+    }
+  } else {
+    for (uint32_t i = first; i < first + count; i++) {
+      float t;
+      cn->tri_tests++;
+      if (hit_tri(r, &sc->tris[i], tmin, best->t, &t)) {
+        best->hit = 1; best->is_sphere = 0; best->slot = i; best->t = t;
+      }
+    }
+  }
+}
+
+/* Closest hit by ordered stack traversal of the flattened BVH2 (row a3):
+ * one node fetch tests both children; both hit -> nearer first (tie: child 0),
+ * the other is pushed; a popped entry is visited without any re-test. */
+static hit_t intersect_bvh(const scene_t *sc, const ray_t *r, float tmin, counters_t *cn) {
+  hit_t best = {0, 0, 0, INFINITY};
+  uint32_t stack[RTGPU_MAX_TREE_DEPTH + 2];
+  int sp = 0;
+  uint32_t cur = 0; /* root */
+  for (;;) {
+    if (cur & RTGPU_REF_LEAF) {
+      leaf_intersect(sc, r, cur, tmin, &best, cn);
+    } else {
+      const rtgpu_node *n = &sc->nodes[cur];
+      float tn0, tn1;
+      cn->nodes++;
+      int h0 = slab(r, n->lo0, n->hi0, tmin, best.t, &tn0) && n->child0 != RTGPU_REF_EMPTY;
+      int h1 = slab(r, n->lo1, n->hi1, tmin, best.t, &tn1) && n->child1 != RTGPU_REF_EMPTY;
+      if (h0 && h1) {
+        if (tn1 < tn0) { stack[sp++] = n->child0; cur = n->child1; }
+        else           { stack[sp++] = n->child1; cur = n->child0; }
+        continue;
+      }
+      if (h0) { cur = n->child0; continue; }
+      if (h1) { cur = n->child1; continue; }
+    }
+    if (sp == 0) break;
+    cur = stack[--sp];
+  }
+  return best;
+}
+
+/* Independent check of builder + traversal: test every primitive, no BVH.
+ * Same per-primitive tests; visiting order = leaf-array order (spheres, then
+ * triangles), so only exact-t ties between primitives can differ from the BVH. */
+static hit_t intersect_brute(const scene_t *sc, const ray_t *r, float tmin, counters_t *cn) {
+  hit_t best = {0, 0, 0, INFINITY};
+  for (uint64_t i = 0; i < sc->n_sphs; i++) {
+    float t;
+    cn->sphere_tests++;
+    if (hit_sphere(r, &sc->sphs[i], tmin, best.t, &t)) {
+      best.hit = 1; best.is_sphere = 1; best.slot = (uint32_t)i; best.t = t;
+    }
+  }
+  for (uint64_t i = 0; i < sc->n_tris; i++) {
+    float t;
+    cn->tri_tests++;
+    if (hit_tri(r, &sc->tris[i], tmin, best.t, &t)) {
+      best.hit = 1; best.is_sphere = 0; best.slot = (uint32_t)i; best.t = t;
+    }
+  }
+  return best;
+}
+
+/* ---- sampling ------------------------------------------------------------------- */
+
+/* Uniform direction on the unit sphere without trigonometry (G. Marsaglia,
+ * "Choosing a point from the surface of a sphere", 1972): (a,b) uniform in the
+ * unit disk by rejection (at most 8 tries, then the pole), s = a^2+b^2,
+ * result (2a sqrt(1-s), 2b sqrt(1-s), 1-2s). */
+static inline v3 random_unit_vector(rng_t *rng) {
+  float a = 0.0f, b = 0.0f, s = 0.0f;
+  for (int i = 0; i < 8; i++) {
+    float ta = u01(rng) * 2.0f - 1.0f;
+    float tb = u01(rng) * 2.0f - 1.0f;
+    float ts = ta * ta + tb * tb;
+    if (ts < 1.0f) { a = ta; b = tb; s = ts; break; }
+  }
+  float f = 2.0f * sqrtf(1.0f - s);
+  v3 r = {a * f, b * f, 1.0f - 2.0f * s};
+  return r;
+}
+
+static inline v3 reflect(v3 d, v3 n) {
+  float k = 2.0f * v3_dot(d, n);
+  return v3_sub(d, v3_scale(n, k));
+}
+
+/* ---- one path (rows a1, a6, a8) ---------------------------------------------------- */
+
+typedef struct {
+  const scene_t *sc;
+  const rtgpu_camera *cam;
+  const rtgpu_settings *st;
+  float inv_w, inv_h;
+  int brute;
+} job_t;
+
+static v3 trace_path(const job_t *J, uint32_t x, uint32_t y, uint32_t sample, uint32_t *primary_id,
+                     counters_t *cn) {
+  const rtgpu_settings *st = J->st;
+  const rtgpu_camera *cam = J->cam;
+  rng_t rng = {path_key(y * st->width + x, sample, st->seed), 0};
+  v3 L = {0.0f, 0.0f, 0.0f};
+  cn->paths++;
+
+  /* camera ray (row a1) */
+  float jx = u01(&rng), jy = u01(&rng);
+  float sx = ((float)x + jx) * J->inv_w;
+  float sy = ((float)y + jy) * J->inv_h;
+  ray_t r;
+  v3 org = v3_from(cam->origin);
+  v3 dir = v3_sub(v3_add(v3_add(v3_from(cam->lower_left), v3_scale(v3_from(cam->horizontal), sx)),
+                         v3_scale(v3_from(cam->vertical), sy)),
+                  org);
+  r.o = org;
+  if (cam->lens_radius > 0.0f) {
+    float a = 0.0f, b = 0.0f;
+    for (int i = 0; i < 8; i++) {
+      float ta = u01(&rng) * 2.0f - 1.0f;
+      float tb = u01(&rng) * 2.0f - 1.0f;
+      if (ta * ta + tb * tb < 1.0f) { a = ta; b = tb; break; }
+    }
+    float ra = a * cam->lens_radius, rb = b * cam->lens_radius;
+    v3 off = v3_add(v3_scale(v3_from(cam->u), ra), v3_scale(v3_from(cam->v), rb));
+    r.o = v3_add(org, off);
+    dir = v3_sub(dir, off);
+  }
+  r.d = v3_normalize(dir);
+
+  v3 thr = {1.0f, 1.0f, 1.0f};
+  *primary_id = RTGPU_NO_HIT;
+  for (uint32_t bounce = 0; bounce < st->max_depth; bounce++) {
+    ray_prepare(&r);
+    cn->rays++;
+    hit_t h = J->brute ? intersect_brute(J->sc, &r, st->tmin, cn)
+                       : intersect_bvh(J->sc, &r, st->tmin, cn);
+    if (!h.hit) {
+      /* sky gradient miss shader */
+      float t = 0.5f * (r.d.y + 1.0f);
+      float a = 1.0f - t;
+      v3 sky = {st->sky_bottom[0] * a + st->sky_top[0] * t, st->sky_bottom[1] * a + st->sky_top[1] * t,
+                st->sky_bottom[2] * a + st->sky_top[2] * t};
+      L = v3_mul(thr, sky);
+      break;
+    }
+    /* surface point, geometric normal, ids */
+    v3 p = v3_add(r.o, v3_scale(r.d, h.t));
+    v3 n;
+    uint32_t prim, mat;
+    if (h.is_sphere) {
+      const rtgpu_sph *s = &J->sc->sphs[h.slot];
+      v3 c = {s->c[0], s->c[1], s->c[2]};
+      float inv_r = 1.0f / s->r;
+      n = v3_scale(v3_sub(p, c), inv_r);
+      prim = J->sc->sph_meta[2 * h.slot];
+      mat = J->sc->sph_meta[2 * h.slot + 1];
+    } else {
+      const rtgpu_tri *tr = &J->sc->tris[h.slot];
+      n = v3_normalize(v3_cross(v3_from(tr->e1), v3_from(tr->e2)));
+      prim = tr->prim_id;
+      mat = tr->material;
+    }
+    if (bounce == 0) *primary_id = prim;
+    float dn = v3_dot(r.d, n);
+    int front = dn < 0.0f;
+    if (!front) n = v3_neg(n);
+
+    /* scatter (row a6) */
+    const rtgpu_material *m = &J->sc->mats[mat];
+    v3 albedo = v3_from(m->albedo);
+    v3 nd;
+    cn->scatters++;
+    if (m->type == RTGPU_MAT_LAMBERTIAN) {
+      v3 ruv = random_unit_vector(&rng);
+      v3 sd = v3_add(n, ruv);
+      if (fabsf(sd.x) < 1e-8f && fabsf(sd.y) < 1e-8f && fabsf(sd.z) < 1e-8f) sd = n;
+      nd = v3_normalize(sd);
+    } else if (m->type == RTGPU_MAT_METAL) {
+      v3 rf = v3_normalize(reflect(r.d, n));
+      if (m->param > 0.0f) {
+        v3 ruv = random_unit_vector(&rng);
+        rf = v3_add(rf, v3_scale(ruv, m->param));
+      }
+      if (!(v3_dot(rf, n) > 0.0f)) break; /* absorbed: L stays 0 */
+      nd = v3_normalize(rf);
+    } else {
+      float ri = front ? 1.0f / m->param : m->param;
+      float cos_t = fminf(-v3_dot(r.d, n), 1.0f);
+      float sin_t = sqrtf(1.0f - cos_t * cos_t);
+      int cannot = ri * sin_t > 1.0f;
+      float r0 = (1.0f - ri) / (1.0f + ri);
+      r0 = r0 * r0;
+      float xx = 1.0f - cos_t;
+      float x2 = xx * xx;
+      float x5 = x2 * x2 * xx;
+      float refl = r0 + (1.0f - r0) * x5;
+      float u = u01(&rng); /* always drawn */
+      v3 sd;
+      if (cannot || refl > u) {
+        sd = reflect(r.d, n);
+      } else {
+        v3 perp = v3_scale(v3_add(r.d, v3_scale(n, cos_t)), ri);
+        float par = -sqrtf(fabsf(1.0f - v3_dot(perp, perp)));
+        sd = v3_add(perp, v3_scale(n, par));
+      }
+      nd = v3_normalize(sd);
+    }
+    thr = v3_mul(thr, albedo);
+    r.o = p;
+    r.d = nd;
+  }
+  return L;
+}
+
+/* ---- frame ------------------------------------------------------------------------- */
+
+/*
+ * Renders pixels x in [x0,x1), y in [y0,y1) of the width*height image into
+ * accum (float4 per pixel, image layout, row 0 = bottom) and prim_id (u32 per
+ * pixel, primary hit of sample `sample_offset`).  Pixels outside the crop, or
+ * in tiles another rank owns, are left untouched.  Per pixel the frame sum is
+ * formed sequentially over samples (s = 0..spp-1), then
+ *   out = (ACCUMULATE ? in : 0) + (sum.r, sum.g, sum.b, (f32)spp).
+ */
+RTO_API int rto_render(const rtgpu_flat_scene *fs, const rtgpu_camera *cam, const rtgpu_settings *st,
+                       float *accum, uint32_t *prim_id, rtgpu_stats *stats, uint32_t x0, uint32_t y0,
+                       uint32_t x1, uint32_t y1, int brute_force, int nthreads) {
+  scene_t sc;
+  sc.nodes = (const rtgpu_node *)fs->nodes;
+  sc.tris = (const rtgpu_tri *)fs->tris;
+  sc.sphs = (const rtgpu_sph *)fs->spheres;
+  sc.sph_meta = fs->sphere_meta;
+  sc.mats = (const rtgpu_material *)fs->materials;
+  sc.n_nodes = fs->n_nodes; sc.n_tris = fs->n_tris; sc.n_sphs = fs->n_spheres; sc.n_mats = fs->n_materials;
+  if (!st->width || !st->height || !st->tile_size || !st->world_size || st->rank >= st->world_size)
+    return 1;
+  if (x1 > st->width) x1 = st->width;
+  if (y1 > st->height) y1 = st->height;
+
+  job_t J;
+  J.sc = &sc; J.cam = cam; J.st = st; J.brute = brute_force;
+  J.inv_w = 1.0f / (float)st->width;
+  J.inv_h = 1.0f / (float)st->height;
+  uint32_t tiles_x = (st->width + st->tile_size - 1) / st->tile_size;
+
+  counters_t total;
+  memset(&total, 0, sizeof(total));
+  if (nthreads < 1) nthreads = 1;
+#ifdef _OPENMP
+#pragma omp parallel num_threads(nthreads)
+#endif
+  {
+    counters_t cn;
+    memset(&cn, 0, sizeof(cn));
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 1)
+#endif
+    for (int64_t yy = (int64_t)y0; yy < (int64_t)y1; yy++) {
+      uint32_t y = (uint32_t)yy;
+      for (uint32_t x = x0; x < x1; x++) {
+        uint32_t tile = (y / st->tile_size) * tiles_x + x / st->tile_size;
+        if (tile % st->world_size != st->rank) continue;
+        v3 sum = {0.0f, 0.0f, 0.0f};
+        uint32_t first_id = RTGPU_NO_HIT;
+        for (uint32_t s = 0; s < st->spp; s++) {
+          uint32_t id;
+          v3 L = trace_path(&J, x, y, st->sample_offset + s, &id, &cn);
+          if (s == 0) first_id = id;
+          sum = v3_add(sum, L);
+        }
+        size_t p = (size_t)y * st->width + x;
+        if (accum) {
+          float *o = accum + 4 * p;
+          if (st->flags & RTGPU_FLAG_ACCUMULATE) {
+            o[0] = o[0] + sum.x; o[1] = o[1] + sum.y; o[2] = o[2] + sum.z; o[3] = o[3] + (float)st->spp;
+          } else {
+            o[0] = sum.x; o[1] = sum.y; o[2] = sum.z; o[3] = (float)st->spp;
+          }
+        }
+        if (prim_id) prim_id[p] = first_id;
+      }
+    }
+#ifdef _OPENMP
+#pragma omp critical
+#endif
+    {
+      total.paths += cn.paths; total.rays += cn.rays; total.nodes += cn.nodes;
+      total.tri_tests += cn.tri_tests; total.sphere_tests += cn.sphere_tests;
+      total.scatters += cn.scatters;
+    }
+  }
+  if (stats) {
+    stats->paths = total.paths; stats->rays = total.rays; stats->nodes = total.nodes;
+    stats->tri_tests = total.tri_tests; stats->sphere_tests = total.sphere_tests;
+    stats->scatters = total.scatters;
+  }
+  return 0;
+}
+
+/* Resolve (row a8): mean, gamma 2, clamp, 8 bits per channel, 0xRRGGBBAA
+ * (run_tree/data/shaders/shaders.hlsl:18-25 unpacks exactly this). */
+RTO_API void rto_resolve_rgba8(const float *accum, uint32_t *rgba8, uint64_t n_pixels) {
+  for (uint64_t i = 0; i < n_pixels; i++) {
+    const float *a = accum + 4 * i;
+    uint32_t px = 0xFFu;
+    if (a[3] > 0.0f) {
+      uint32_t ch[3];
+      for (int k = 0; k < 3; k++) {
+        float c = sqrtf(fmaxf(a[k] / a[3], 0.0f));
+        c = fminf(c, 0.999f);
+        ch[k] = (uint32_t)(256.0f * c);
+      }
+      px = (ch[0] << 24) | (ch[1] << 16) | (ch[2] << 8) | 0xFFu;
+    }
+    rgba8[i] = px;
+  }
+}
+
+/* Structural validation of a flattened BVH (checks the builder, independent of
+ * any ray): every reference in range, every primitive inside its leaf box,
+ * every node's child boxes inside the box its parent stores for it, every
+ * primitive referenced exactly once.  Returns 0 if valid, else a code. */
+static int box_inside(const float *lo, const float *hi, const float *plo, const float *phi) {
+  for (int k = 0; k < 3; k++)
+    if (lo[k] < plo[k] || hi[k] > phi[k]) return 0;
+  return 1;
+}
+
+RTO_API int rto_validate_bvh(const rtgpu_flat_scene *fs, uint32_t *max_depth_out) {
+  const rtgpu_node *nodes = (const rtgpu_node *)fs->nodes;
+  const rtgpu_tri *tris = (const rtgpu_tri *)fs->tris;
+  const rtgpu_sph *sphs = (const rtgpu_sph *)fs->spheres;
+  uint8_t *seen_t = (uint8_t *)calloc(fs->n_tris + 1, 1);
+  uint8_t *seen_s = (uint8_t *)calloc(fs->n_spheres + 1, 1);
+  typedef struct { uint32_t ref; uint32_t depth; float lo[3], hi[3]; } item_t;
+  size_t cap = 2 * (size_t)fs->n_nodes + 16, sp = 0;
+  item_t *stack = (item_t *)malloc(cap * sizeof(item_t));
+  int rc = 0;
+  uint32_t maxd = 0;
+  item_t root = {0, 0, {-INFINITY, -INFINITY, -INFINITY}, {INFINITY, INFINITY, INFINITY}};
+  stack[sp++] = root;
+  while (sp && !rc) {
+    item_t it = stack[--sp];
+    if (it.ref == RTGPU_REF_EMPTY) continue;
+    if (it.ref & RTGPU_REF_LEAF) {
+      uint32_t first = RTGPU_REF_FIRST(it.ref), count = RTGPU_REF_COUNT(it.ref);
+      if (it.depth > maxd) maxd = it.depth;
+      for (uint32_t i = first; i < first + count && !rc; i++) {
+        float lo[3], hi[3];
+        if (it.ref & RTGPU_REF_SPHERE) {
+          if (i >= fs->n_spheres) { rc = 2; break; }
+          if (seen_s[i]++) { rc = 3; break; }
+          for (int k = 0; k < 3; k++) { lo[k] = sphs[i].c[k] - sphs[i].r; hi[k] = sphs[i].c[k] + sphs[i].r; }
+        } else {
+          if (i >= fs->n_tris) { rc = 2; break; }
+          if (seen_t[i]++) { rc = 3; break; }
+          for (int k = 0; k < 3; k++) {
+            float a = tris[i].v0[k], b = a + tris[i].e1[k], c = a + tris[i].e2[k];
+            /* v0+e rounds; allow the builder's padding to absorb 1 ulp */
+            lo[k] = fminf(a, fminf(b, c)); hi[k] = fmaxf(a, fmaxf(b, c));
+            float e = fmaxf(fmaxf(fabsf(lo[k]), fabsf(hi[k])), 1.0f) * 0x1p-22f;
+            lo[k] += e; hi[k] -= e;
+            if (lo[k] > hi[k]) lo[k] = hi[k] = 0.5f * (lo[k] + hi[k]);
+          }
+        }
+        if (!box_inside(lo, hi, it.lo, it.hi)) rc = 4;
+      }
+      continue;
+    }
+    if (it.ref >= fs->n_nodes) { rc = 5; break; }
+    if (it.depth > RTGPU_MAX_TREE_DEPTH) { rc = 6; break; }
+    const rtgpu_node *n = &nodes[it.ref];
+    if (n->child0 != RTGPU_REF_EMPTY && !box_inside(n->lo0, n->hi0, it.lo, it.hi)) { rc = 7; break; }
+    if (n->child1 != RTGPU_REF_EMPTY && !box_inside(n->lo1, n->hi1, it.lo, it.hi)) { rc = 7; break; }
+    if (sp + 2 > cap) { rc = 8; break; }
+    item_t a = {n->child0, it.depth + 1, {n->lo0[0], n->lo0[1], n->lo0[2]}, {n->hi0[0], n->hi0[1], n->hi0[2]}};
+    item_t b = {n->child1, it.depth + 1, {n->lo1[0], n->lo1[1], n->lo1[2]}, {n->hi1[0], n->hi1[1], n->hi1[2]}};
+    stack[sp++] = a;
+    stack[sp++] = b;
+  }
+  if (!rc) {
+    for (uint64_t i = 0; i < fs->n_tris; i++) if (seen_t[i] != 1) { rc = 9; break; }
+    for (uint64_t i = 0; i < fs->n_spheres; i++) if (seen_s[i] != 1) { rc = 9; break; }
+  }
+  if (max_depth_out) *max_depth_out = maxd;
+  free(seen_t); free(seen_s); free(stack);
+  return rc;
+}
+
+RTO_API int rto_has_openmp(void) {
+#ifdef _OPENMP
+  return 1;
+#else
+  return 0;
+#endif
+}

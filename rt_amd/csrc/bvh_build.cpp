@@ -1,0 +1,376 @@
+// bvh_build.cpp — host side of SURVEY.md §8a row a2: SAH-binned BVH2 build and
+// flatten into the HBM layout of include/rtgpu_format.h.
+//
+// No reference counterpart exists (the reference has no BVH).
+// Conventions followed: POD arrays, zero-initialised long-lived allocations as
+// alloc_perm does (code/base/memory.cxx:23-34), f32 arithmetic only.
+//
+// Determinism: single-threaded, no data-dependent container ordering, so the
+// same scene always flattens to the same bytes (the oracle walks these bytes).
+#include "rtgpu_internal.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+namespace rtgpu {
+
+namespace {
+
+struct Box {
+  float lo[3], hi[3];
+  void reset() {
+    for (int k = 0; k < 3; k++) { lo[k] = INFINITY; hi[k] = -INFINITY; }
+  }
+  void grow(const float *l, const float *h) {
+    for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], l[k]); hi[k] = std::max(hi[k], h[k]); }
+  }
+  void grow(const Box &b) { grow(b.lo, b.hi); }
+  float half_area() const {
+    float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    if (!(dx >= 0.f) || !(dy >= 0.f) || !(dz >= 0.f)) return 0.f;
+    return dx * dy + dy * dz + dz * dx;
+  }
+};
+
+struct BuildPrim {
+  Box      box;       // padded primitive AABB
+  float    c[3];      // centroid
+  uint32_t index;     // index into the caller's sphere / triangle array
+  uint32_t is_sphere;
+};
+
+constexpr int   kBins      = 16;
+constexpr int   kMaxLeaf   = 4;
+constexpr float kTravCost  = 1.0f;
+constexpr float kIsectCost = 1.0f;
+constexpr uint32_t kMedianDepth = 40;  // below this depth: median splits only
+
+// Pad so that the fma-form slab test of the trace loop (DESIGN.md "slab test")
+// stays conservative: 2^-18 relative, with an absolute floor.
+inline void pad_box(Box &b) {
+  for (int k = 0; k < 3; k++) {
+    float m = std::max(std::max(std::fabs(b.lo[k]), std::fabs(b.hi[k])), 1.0f);
+    float e = m * (1.0f / 262144.0f);
+    b.lo[k] -= e;
+    b.hi[k] += e;
+  }
+}
+
+struct Builder {
+  const rtgpu_scene_desc *scene;
+  std::vector<BuildPrim>  prims;
+  std::vector<rtgpu_node> nodes;
+  std::vector<rtgpu_tri>  tris;
+  std::vector<rtgpu_sph>  sphs;
+  std::vector<uint32_t>   sph_meta;
+  uint32_t                max_depth = 0;
+
+  uint32_t make_leaf(size_t b, size_t e, uint32_t depth) {
+    max_depth = std::max(max_depth, depth);
+    uint32_t n = (uint32_t)(e - b);
+    bool sph = prims[b].is_sphere != 0;
+    uint32_t first;
+    if (sph) {
+      first = (uint32_t)sphs.size();
+      for (size_t i = b; i < e; i++) {
+        const rtgpu_sphere &s = scene->spheres[prims[i].index];
+        rtgpu_sph r;
+        r.c[0] = s.center[0]; r.c[1] = s.center[1]; r.c[2] = s.center[2]; r.r = s.radius;
+        sphs.push_back(r);
+        sph_meta.push_back(prims[i].index);  // prim id: spheres come first
+        sph_meta.push_back(s.material);
+      }
+    } else {
+      first = (uint32_t)tris.size();
+      for (size_t i = b; i < e; i++) {
+        const rtgpu_triangle &t = scene->triangles[prims[i].index];
+        rtgpu_tri r;
+        for (int k = 0; k < 3; k++) {
+          r.v0[k] = t.v0[k];
+          r.e1[k] = t.v1[k] - t.v0[k];
+          r.e2[k] = t.v2[k] - t.v0[k];
+        }
+        r.prim_id  = (uint32_t)scene->n_spheres + prims[i].index;
+        r.material = t.material;
+        r._pad     = 0;
+        tris.push_back(r);
+      }
+    }
+    return RTGPU_REF_LEAF | (sph ? RTGPU_REF_SPHERE : 0u) | ((n - 1u) << 27) | first;
+  }
+
+  // Returns the child reference for prims[b, e) and its bounds.
+  uint32_t build(size_t b, size_t e, uint32_t depth, Box &bounds) {
+    size_t n = e - b;
+    Box cb;
+    bounds.reset();
+    cb.reset();
+    size_t n_sph = 0;
+    for (size_t i = b; i < e; i++) {
+      bounds.grow(prims[i].box);
+      cb.grow(prims[i].c, prims[i].c);
+      n_sph += prims[i].is_sphere;
+    }
+    bool mixed = n_sph != 0 && n_sph != n;
+    if (n == 1) return make_leaf(b, e, depth);
+
+    size_t mid = 0;
+    bool   have_split = false;
+
+    if (mixed && n <= (size_t)kMaxLeaf) {
+      // small mixed cluster: split by type so each leaf holds one type
+      auto it = std::stable_partition(prims.begin() + b, prims.begin() + e,
+                                      [](const BuildPrim &p) { return p.is_sphere != 0; });
+      mid = (size_t)(it - prims.begin());
+      have_split = true;
+    }
+
+    if (!have_split && depth < kMedianDepth) {
+      // binned SAH over the three axes
+      float best_cost = INFINITY;
+      int   best_axis = -1, best_bin = -1;
+      float parent_area = bounds.half_area();
+      for (int axis = 0; axis < 3; axis++) {
+        float lo = cb.lo[axis], ext = cb.hi[axis] - cb.lo[axis];
+        if (!(ext > 0.f)) continue;
+        float scale = (float)kBins / ext;
+        Box   bin_box[kBins];
+        size_t bin_cnt[kBins];
+        for (int i = 0; i < kBins; i++) { bin_box[i].reset(); bin_cnt[i] = 0; }
+        for (size_t i = b; i < e; i++) {
+          int bi = (int)((prims[i].c[axis] - lo) * scale);
+          bi = std::min(std::max(bi, 0), kBins - 1);
+          bin_box[bi].grow(prims[i].box);
+          bin_cnt[bi]++;
+        }
+        float  right_area[kBins];
+        size_t right_cnt[kBins];
+        Box    acc;
+        acc.reset();
+        size_t cnt = 0;
+        for (int i = kBins - 1; i >= 1; i--) {
+          acc.grow(bin_box[i]);
+          cnt += bin_cnt[i];
+          right_area[i] = acc.half_area();
+          right_cnt[i]  = cnt;
+        }
+        acc.reset();
+        cnt = 0;
+        for (int i = 0; i < kBins - 1; i++) {
+          acc.grow(bin_box[i]);
+          cnt += bin_cnt[i];
+          if (cnt == 0 || right_cnt[i + 1] == 0) continue;
+          float cost = acc.half_area() * (float)cnt + right_area[i + 1] * (float)right_cnt[i + 1];
+          if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = i; }
+        }
+      }
+      if (best_axis >= 0) {
+        float split_cost = kTravCost + kIsectCost * best_cost / std::max(parent_area, 1e-30f);
+        float leaf_cost  = kIsectCost * (float)n;
+        if (n <= (size_t)kMaxLeaf && !mixed && leaf_cost <= split_cost)
+          return make_leaf(b, e, depth);
+        float lo = cb.lo[best_axis], ext = cb.hi[best_axis] - cb.lo[best_axis];
+        float scale = (float)kBins / ext;
+        auto it = std::stable_partition(
+            prims.begin() + b, prims.begin() + e, [&](const BuildPrim &p) {
+              int bi = (int)((p.c[best_axis] - lo) * scale);
+              bi = std::min(std::max(bi, 0), kBins - 1);
+              return bi <= best_bin;
+            });
+        mid = (size_t)(it - prims.begin());
+        have_split = mid > b && mid < e;
+      }
+    }
+
+    if (!have_split) {
+      if (n <= (size_t)kMaxLeaf && !mixed) return make_leaf(b, e, depth);
+      // median split along the widest centroid axis (also the depth-bounded path)
+      int axis = 0;
+      float best = -1.f;
+      for (int k = 0; k < 3; k++) {
+        float ext = cb.hi[k] - cb.lo[k];
+        if (ext > best) { best = ext; axis = k; }
+      }
+      mid = b + n / 2;
+      if (mixed && !(best > 0.f)) {
+        auto it = std::stable_partition(prims.begin() + b, prims.begin() + e,
+                                        [](const BuildPrim &p) { return p.is_sphere != 0; });
+        mid = (size_t)(it - prims.begin());
+      } else {
+        std::nth_element(prims.begin() + b, prims.begin() + mid, prims.begin() + e,
+                         [axis](const BuildPrim &x, const BuildPrim &y) {
+                           if (x.c[axis] != y.c[axis]) return x.c[axis] < y.c[axis];
+                           if (x.is_sphere != y.is_sphere) return x.is_sphere > y.is_sphere;
+                           return x.index < y.index;
+                         });
+      }
+    }
+
+    uint32_t me = (uint32_t)nodes.size();
+    nodes.emplace_back();
+    Box b0, b1;
+    uint32_t c0 = build(b, mid, depth + 1, b0);
+    uint32_t c1 = build(mid, e, depth + 1, b1);
+    rtgpu_node &nd = nodes[me];
+    for (int k = 0; k < 3; k++) {
+      nd.lo0[k] = b0.lo[k]; nd.hi0[k] = b0.hi[k];
+      nd.lo1[k] = b1.lo[k]; nd.hi1[k] = b1.hi[k];
+    }
+    nd.child0 = c0;
+    nd.child1 = c1;
+    nd._pad[0] = nd._pad[1] = 0;
+    return me;
+  }
+};
+
+template <typename T>
+T *copy_out(const std::vector<T> &v, size_t min_elems = 1) {
+  // zeroed, 64-byte aligned, never empty (callers may upload n+pad elements)
+  size_t n = std::max(v.size(), min_elems);
+  size_t bytes = ((n * sizeof(T) + 63) / 64) * 64;
+  void *p = std::aligned_alloc(64, bytes);
+  if (!p) return nullptr;
+  std::memset(p, 0, bytes);
+  if (!v.empty()) std::memcpy(p, v.data(), v.size() * sizeof(T));
+  return (T *)p;
+}
+
+}  // namespace
+
+int flatten_scene(const rtgpu_scene_desc *scene, rtgpu_flat_scene *out, std::string &err) {
+  std::memset(out, 0, sizeof(*out));
+  if (!scene) { err = "scene is NULL"; return 1; }
+  if ((scene->n_spheres && !scene->spheres) || (scene->n_triangles && !scene->triangles) ||
+      (scene->n_materials && !scene->materials)) {
+    err = "scene array pointer is NULL with a non-zero count";
+    return 1;
+  }
+  if (scene->n_spheres > RTGPU_MAX_PRIMS_PER_TYPE || scene->n_triangles > RTGPU_MAX_PRIMS_PER_TYPE) {
+    err = "too many primitives (limit 134,217,720 per type)";
+    return 1;
+  }
+  if (scene->n_materials == 0 && (scene->n_spheres || scene->n_triangles)) {
+    err = "scene has primitives but no materials";
+    return 1;
+  }
+  auto t0 = std::chrono::steady_clock::now();
+
+  Builder B;
+  B.scene = scene;
+  B.prims.reserve(scene->n_spheres + scene->n_triangles);
+  for (uint64_t i = 0; i < scene->n_spheres; i++) {
+    const rtgpu_sphere &s = scene->spheres[i];
+    if (s.material >= scene->n_materials) { err = "sphere material index out of range"; return 1; }
+    if (!(s.radius > 0.f) || !std::isfinite(s.radius) || !std::isfinite(s.center[0]) ||
+        !std::isfinite(s.center[1]) || !std::isfinite(s.center[2])) {
+      err = "sphere with non-finite centre or non-positive radius";
+      return 1;
+    }
+    BuildPrim p;
+    for (int k = 0; k < 3; k++) {
+      p.box.lo[k] = s.center[k] - s.radius;
+      p.box.hi[k] = s.center[k] + s.radius;
+      p.c[k]      = s.center[k];
+    }
+    pad_box(p.box);
+    p.index = (uint32_t)i;
+    p.is_sphere = 1;
+    B.prims.push_back(p);
+  }
+  for (uint64_t i = 0; i < scene->n_triangles; i++) {
+    const rtgpu_triangle &t = scene->triangles[i];
+    if (t.material >= scene->n_materials) { err = "triangle material index out of range"; return 1; }
+    BuildPrim p;
+    for (int k = 0; k < 3; k++) {
+      if (!std::isfinite(t.v0[k]) || !std::isfinite(t.v1[k]) || !std::isfinite(t.v2[k])) {
+        err = "triangle with a non-finite vertex";
+        return 1;
+      }
+      p.box.lo[k] = std::min(t.v0[k], std::min(t.v1[k], t.v2[k]));
+      p.box.hi[k] = std::max(t.v0[k], std::max(t.v1[k], t.v2[k]));
+      p.c[k]      = (p.box.lo[k] + p.box.hi[k]) * 0.5f;
+    }
+    pad_box(p.box);
+    p.index = (uint32_t)i;
+    p.is_sphere = 0;
+    B.prims.push_back(p);
+  }
+
+  size_t n = B.prims.size();
+  B.nodes.reserve(n ? n : 1);
+  B.tris.reserve(scene->n_triangles);
+  B.sphs.reserve(scene->n_spheres);
+  B.sph_meta.reserve(scene->n_spheres * 2);
+
+  const float inv_lo = 1e30f, inv_hi = -1e30f;  // inverted box: never hit
+  if (n <= 1) {
+    rtgpu_node root;
+    std::memset(&root, 0, sizeof(root));
+    for (int k = 0; k < 3; k++) {
+      root.lo0[k] = root.lo1[k] = inv_lo;
+      root.hi0[k] = root.hi1[k] = inv_hi;
+    }
+    root.child0 = root.child1 = RTGPU_REF_EMPTY;
+    if (n == 1) {
+      for (int k = 0; k < 3; k++) { root.lo0[k] = B.prims[0].box.lo[k]; root.hi0[k] = B.prims[0].box.hi[k]; }
+      root.child0 = B.make_leaf(0, 1, 1);
+    }
+    B.nodes.push_back(root);
+  } else {
+    Box bounds;
+    uint32_t r = B.build(0, n, 0, bounds);
+    if (r != 0) { err = "internal: root is not node 0"; return 1; }
+  }
+  if (B.max_depth > RTGPU_MAX_TREE_DEPTH) {
+    err = "internal: BVH deeper than RTGPU_MAX_TREE_DEPTH";
+    return 1;
+  }
+
+  std::vector<rtgpu_material> mats(scene->materials, scene->materials + scene->n_materials);
+  // +8 zeroed records behind the leaf-ordered arrays: a leaf reference can
+  // name at most 8 primitives, so even a corrupt count cannot read past them.
+  out->nodes       = copy_out(B.nodes);
+  out->n_nodes     = B.nodes.size();
+  out->tris        = copy_out(B.tris, B.tris.size() + 8);
+  out->n_tris      = B.tris.size();
+  out->spheres     = copy_out(B.sphs, B.sphs.size() + 8);
+  out->n_spheres   = B.sphs.size();
+  out->sphere_meta = copy_out(B.sph_meta, B.sph_meta.size() + 16);
+  out->materials   = copy_out(mats);
+  out->n_materials = mats.size();
+  out->max_depth   = B.max_depth;
+  if (!out->nodes || !out->tris || !out->spheres || !out->sphere_meta || !out->materials) {
+    free_flat_scene(out);
+    err = "out of host memory while flattening the scene";
+    return 1;
+  }
+  out->build_ms =
+      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return 0;
+}
+
+void free_flat_scene(rtgpu_flat_scene *fs) {
+  if (!fs) return;
+  std::free((void *)fs->nodes);
+  std::free((void *)fs->tris);
+  std::free((void *)fs->spheres);
+  std::free((void *)fs->sphere_meta);
+  std::free((void *)fs->materials);
+  std::memset(fs, 0, sizeof(*fs));
+}
+
+}  // namespace rtgpu
+
+extern "C" int rtgpu_flatten_scene_host(const rtgpu_scene_desc *scene, rtgpu_flat_scene *out) {
+  std::string err;
+  if (!out) return 1;
+  int rc = rtgpu::flatten_scene(scene, out, err);
+  if (rc) rtgpu::set_global_error(err);
+  return rc;
+}
+
+extern "C" void rtgpu_flat_scene_free(rtgpu_flat_scene *fs) { rtgpu::free_flat_scene(fs); }

@@ -1,0 +1,796 @@
+// rtgpu_kernels.hip — the per-pixel trace loop on gfx950 (SURVEY.md §8a rows
+// a1, a3-a8) and the C ABI around it (include/rtgpu.h).
+//
+// No reference counterpart exists for any of this; the written
+// specification is the CPU oracle (oracle/rt_oracle.c), which this kernel has
+// to match bit for bit: same f32 operations in the same order, no contraction
+// (this file is compiled with -ffp-contract=off; the only fused operations are
+// the explicit __builtin_fmaf of the slab test), IEEE division and sqrt
+// (hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt), the same
+// counter-based integer RNG.  Vector arithmetic follows the reference's
+// rt::Vec3 (code/math/vec.cxx:94-97 dot = mul then x+y+z; :66-69 normalize =
+// v * (1/len); :174-211 component-wise operators).
+//
+// Structure: persistent threads.  Each lane owns one pixel at a time and
+// walks its samples in order (the frame sum is formed sequentially per pixel,
+// which keeps accumulation deterministic); a lane whose pixel is finished
+// draws the next one from a global queue with one atomic per wave
+// (ballot + mbcnt prefix), so waves stay full until the queue is dry.
+// Traversal is a while-while loop over the 64-byte BVH2 nodes with a per-lane
+// short stack in LDS ([entry][thread], conflict-free) that overflows into
+// scratch for the rare deep path.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rtgpu_internal.h"
+
+namespace {
+
+constexpr int      kBlock      = 256;
+constexpr int      kStackLds   = 24;   // entries per lane in LDS
+constexpr int      kStackOvf   = RTGPU_MAX_TREE_DEPTH + 2 - kStackLds;  // rest, in scratch
+constexpr uint32_t kDone       = 0xFFFFFFFFu;  // == RTGPU_REF_EMPTY, has the leaf bit
+
+struct KParams {
+  const float4 *nodes;
+  const float4 *tris;
+  const float4 *sphs;
+  const uint2  *sph_meta;
+  const float4 *mats;
+  float4       *accum;
+  uint32_t     *prim_id;
+  unsigned long long *counters;  // [0] queue head, [1] paths, [2] rays, [3] nodes, [4] tris, [5] sphs, [6] scatters
+  float cam_origin[3], cam_ll[3], cam_hor[3], cam_ver[3], cam_u[3], cam_v[3];
+  float lens_radius;
+  float inv_w, inv_h, tmin;
+  float sky_bottom[3], sky_top[3];
+  uint32_t width, height, spp, sample_offset, max_depth, seed;
+  uint32_t ts_log2, tiles_x, rank, world, n_items, flags;
+};
+
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ V3 ld3(const float *p) { return mk(p[0], p[1], p[2]); }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator*(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ V3 operator*(V3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ V3 neg(V3 a) { return mk(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ float dot(V3 a, V3 b) { a = a * b; return a.x + a.y + a.z; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) {
+  return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ V3 normalize(V3 a) { return a * (1.0f / __builtin_sqrtf(dot(a, a))); }
+__device__ __forceinline__ float fmin_(float a, float b) { return __builtin_fminf(a, b); }
+__device__ __forceinline__ float fmax_(float a, float b) { return __builtin_fmaxf(a, b); }
+
+__device__ __forceinline__ uint32_t pcg(uint32_t v) {
+  uint32_t s = v * 747796405u + 2891336453u;
+  uint32_t w = ((s >> ((s >> 28) + 4u)) ^ s) * 277803737u;
+  return (w >> 22) ^ w;
+}
+
+struct Rng {
+  uint32_t key, ctr;
+  __device__ __forceinline__ float u01() {
+    uint32_t h = pcg(key + ctr * 0x9E3779B9u);
+    ctr++;
+    return (float)(h >> 8) * 0x1p-24f;
+  }
+};
+
+__device__ __forceinline__ float clamp_dir(float d) {
+  return __builtin_fabsf(d) < 1e-30f ? __builtin_copysignf(1e-30f, d) : d;
+}
+
+__device__ __forceinline__ V3 random_unit_vector(Rng &rng) {
+  float a = 0.0f, b = 0.0f, s = 0.0f;
+  bool found = false;
+#pragma unroll 1
+  for (int i = 0; i < 8 && !found; i++) {
+    float ta = rng.u01() * 2.0f - 1.0f;
+    float tb = rng.u01() * 2.0f - 1.0f;
+    float ts = ta * ta + tb * tb;
+    if (ts < 1.0f) { a = ta; b = tb; s = ts; found = true; }
+  }
+  float f = 2.0f * __builtin_sqrtf(1.0f - s);
+  return mk(a * f, b * f, 1.0f - 2.0f * s);
+}
+
+__device__ __forceinline__ V3 reflect(V3 d, V3 n) {
+  float k = 2.0f * dot(d, n);
+  return d - n * k;
+}
+
+__device__ __forceinline__ unsigned lane_id() {
+  return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(kBlock) void trace_kernel(const KParams P) {
+  __shared__ uint32_t lds_stack[kStackLds * kBlock];
+  uint32_t ovf_stack[kStackOvf];
+  const unsigned tid = threadIdx.x;
+  const unsigned lane = lane_id();
+
+  const V3 cam_o = ld3(P.cam_origin), cam_ll = ld3(P.cam_ll), cam_hor = ld3(P.cam_hor),
+           cam_ver = ld3(P.cam_ver);
+  const uint32_t ts = 1u << P.ts_log2;
+  const uint32_t blocks_per_row_log2 = P.ts_log2 - 3u;  // 8x8 pixel blocks per tile row
+
+  // lane state
+  bool done = false, alive = false, have_pixel = false, pixel_valid = false;
+  uint32_t px = 0, py = 0, out_index = 0, sample = 0, bounce = 0, first_id = RTGPU_NO_HIT;
+  V3 sum = mk(0.f, 0.f, 0.f), thr = mk(1.f, 1.f, 1.f), ro = mk(0.f, 0.f, 0.f), rd = mk(0.f, 0.f, 1.f);
+  Rng rng = {0u, 0u};
+  unsigned long long n_paths = 0, n_rays = 0, n_nodes = 0, n_tris = 0, n_sphs = 0, n_scat = 0;
+
+  for (;;) {
+    // ---- (1) lanes without a path in flight: next sample, or next pixel ------
+    bool need_pixel = !alive && !done && (!have_pixel || sample >= P.spp);
+    if (need_pixel && have_pixel) {
+      if (pixel_valid) {
+        float4 o = make_float4(sum.x, sum.y, sum.z, (float)P.spp);
+        if (P.flags & RTGPU_FLAG_ACCUMULATE) {
+          float4 in = P.accum[out_index];
+          o.x = in.x + o.x; o.y = in.y + o.y; o.z = in.z + o.z; o.w = in.w + o.w;
+        }
+        P.accum[out_index] = o;
+        if (P.prim_id) P.prim_id[out_index] = first_id;
+      }
+      have_pixel = false;
+    }
+    unsigned long long need_mask = __ballot(need_pixel);
+    if (need_mask != 0ull) {  // wave-uniform
+      unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(need_mask >> 32),
+                                                __builtin_amdgcn_mbcnt_lo((unsigned)need_mask, 0u));
+      unsigned leader = (unsigned)__ffsll((long long)need_mask) - 1u;
+      unsigned long long base = 0;
+      if (lane == leader)
+        base = atomicAdd(&P.counters[0], (unsigned long long)__popcll(need_mask));
+      base = __shfl(base, (int)leader, 64);
+      if (need_pixel) {
+        unsigned long long item = base + rank;
+        if (item >= (unsigned long long)P.n_items) {
+          done = true;
+        } else {
+          // item -> (local tile, 8x8 block in tile, pixel in block): lanes of a
+          // wave that fetch together trace one 8x8 pixel block
+          uint32_t it = (uint32_t)item;
+          uint32_t k = it & (ts * ts - 1u), j = it >> (2u * P.ts_log2);
+          uint32_t blk = k >> 6, within = k & 63u;
+          uint32_t tx = ((blk & ((1u << blocks_per_row_log2) - 1u)) << 3) + (within & 7u);
+          uint32_t ty = ((blk >> blocks_per_row_log2) << 3) + (within >> 3);
+          uint32_t tile = P.rank + j * P.world;
+          uint32_t tile_y = tile / P.tiles_x, tile_x = tile - tile_y * P.tiles_x;
+          px = (tile_x << P.ts_log2) + tx;
+          py = (tile_y << P.ts_log2) + ty;
+          pixel_valid = px < P.width && py < P.height;
+          out_index = (P.flags & RTGPU_FLAG_COMPACT) ? (j << (2u * P.ts_log2)) + (ty << P.ts_log2) + tx
+                                                      : py * P.width + px;
+          have_pixel = true;
+          sample = pixel_valid ? 0u : P.spp;  // out-of-image pixel: nothing to trace
+          sum = mk(0.f, 0.f, 0.f);
+          first_id = RTGPU_NO_HIT;
+        }
+      }
+    }
+    if (!alive && !done && have_pixel && sample < P.spp) {
+      // ---- camera ray (row a1) ----
+      rng.key = pcg((P.sample_offset + sample) ^ pcg((py * P.width + px) ^ pcg(P.seed)));
+      rng.ctr = 0;
+      float jx = rng.u01(), jy = rng.u01();
+      float sx = ((float)px + jx) * P.inv_w;
+      float sy = ((float)py + jy) * P.inv_h;
+      V3 dir = ((cam_ll + cam_hor * sx) + cam_ver * sy) - cam_o;
+      ro = cam_o;
+      if (P.lens_radius > 0.0f) {
+        float a = 0.0f, b = 0.0f;
+        bool found = false;
+#pragma unroll 1
+        for (int i = 0; i < 8 && !found; i++) {
+          float ta = rng.u01() * 2.0f - 1.0f;
+          float tb = rng.u01() * 2.0f - 1.0f;
+          if (ta * ta + tb * tb < 1.0f) { a = ta; b = tb; found = true; }
+        }
+        float ra = a * P.lens_radius, rb = b * P.lens_radius;
+        V3 off = ld3(P.cam_u) * ra + ld3(P.cam_v) * rb;
+        ro = cam_o + off;
+        dir = dir - off;
+      }
+      rd = normalize(dir);
+      thr = mk(1.f, 1.f, 1.f);
+      bounce = 0;
+      alive = true;
+      n_paths++;
+    }
+    if (__ballot(alive) == 0ull) break;  // done implies !alive: the whole wave is dry
+
+    if (alive) {
+      // ---- (2) closest hit: ordered while-while traversal (rows a3-a5) --------
+      const V3 inv = mk(1.0f / clamp_dir(rd.x), 1.0f / clamp_dir(rd.y), 1.0f / clamp_dir(rd.z));
+      const V3 noi = mk(-(ro.x * inv.x), -(ro.y * inv.y), -(ro.z * inv.z));
+      float tbest = __builtin_inff();
+      uint32_t hit_slot = 0;
+      int hit_kind = 0;  // 0 none, 1 sphere, 2 triangle
+      uint32_t cur = 0;  // root
+      int sp = 0;
+      n_rays++;
+
+      while (cur != kDone) {
+        while (!(cur & RTGPU_REF_LEAF)) {
+          const float4 *n = P.nodes + (size_t)cur * 4u;
+          float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
+          if (STATS) n_nodes++;
+          // child 0: lo (q0.x q0.y q0.z) hi (q0.w q1.x q1.y); child 1: lo (q1.z q1.w q2.x) hi (q2.y q2.z q2.w)
+          float a0x = __builtin_fmaf(q0.x, inv.x, noi.x), a1x = __builtin_fmaf(q0.w, inv.x, noi.x);
+          float a0y = __builtin_fmaf(q0.y, inv.y, noi.y), a1y = __builtin_fmaf(q1.x, inv.y, noi.y);
+          float a0z = __builtin_fmaf(q0.z, inv.z, noi.z), a1z = __builtin_fmaf(q1.y, inv.z, noi.z);
+          float tn0 = fmax_(fmax_(fmin_(a0x, a1x), fmin_(a0y, a1y)), fmax_(fmin_(a0z, a1z), P.tmin));
+          float tf0 = fmin_(fmin_(fmax_(a0x, a1x), fmax_(a0y, a1y)), fmin_(fmax_(a0z, a1z), tbest));
+          float b0x = __builtin_fmaf(q1.z, inv.x, noi.x), b1x = __builtin_fmaf(q2.y, inv.x, noi.x);
+          float b0y = __builtin_fmaf(q1.w, inv.y, noi.y), b1y = __builtin_fmaf(q2.z, inv.y, noi.y);
+          float b0z = __builtin_fmaf(q2.x, inv.z, noi.z), b1z = __builtin_fmaf(q2.w, inv.z, noi.z);
+          float tn1 = fmax_(fmax_(fmin_(b0x, b1x), fmin_(b0y, b1y)), fmax_(fmin_(b0z, b1z), P.tmin));
+          float tf1 = fmin_(fmin_(fmax_(b0x, b1x), fmax_(b0y, b1y)), fmin_(fmax_(b0z, b1z), tbest));
+          uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
+          bool h0 = (tn0 <= tf0) && (c0 != RTGPU_REF_EMPTY);
+          bool h1 = (tn1 <= tf1) && (c1 != RTGPU_REF_EMPTY);
+          if (h0 && h1) {
+            bool swap = tn1 < tn0;
+            uint32_t nearc = swap ? c1 : c0, farc = swap ? c0 : c1;
+            if (sp < kStackLds) lds_stack[sp * kBlock + tid] = farc;
+            else ovf_stack[sp - kStackLds] = farc;
+            sp++;
+            cur = nearc;
+          } else if (h0) {
+            cur = c0;
+          } else if (h1) {
+            cur = c1;
+          } else if (sp > 0) {
+            sp--;
+            cur = (sp < kStackLds) ? lds_stack[sp * kBlock + tid] : ovf_stack[sp - kStackLds];
+          } else {
+            cur = kDone;
+          }
+        }
+        if (cur != kDone) {
+          uint32_t first = RTGPU_REF_FIRST(cur), count = RTGPU_REF_COUNT(cur);
+          if (cur & RTGPU_REF_SPHERE) {
+#pragma unroll 1
+            for (uint32_t i = first; i < first + count; i++) {
+              float4 s = P.sphs[i];
+              if (STATS) n_sphs++;
+              V3 oc = ro - mk(s.x, s.y, s.z);
+              float hb = dot(oc, rd);
+              float cc = dot(oc, oc) - s.w * s.w;
+              float disc = hb * hb - cc;
+              if (!(disc < 0.0f)) {
+                float sq = __builtin_sqrtf(disc);
+                float t = -hb - sq;
+                bool ok = t > P.tmin && t < tbest;
+                if (!ok) { t = -hb + sq; ok = t > P.tmin && t < tbest; }
+                if (ok) { tbest = t; hit_slot = i; hit_kind = 1; }
+              }
+            }
+          } else {
+#pragma unroll 1
+            for (uint32_t i = first; i < first + count; i++) {
+              const float4 *tp = P.tris + (size_t)i * 3u;
+              float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
+              if (STATS) n_tris++;
+              V3 v0 = mk(t0.x, t0.y, t0.z), e1 = mk(t1.x, t1.y, t1.z), e2 = mk(t2.x, t2.y, t2.z);
+              V3 pvec = cross(rd, e2);
+              float det = dot(e1, pvec);
+              if (!(__builtin_fabsf(det) < 1e-30f)) {
+                float inv_det = 1.0f / det;
+                V3 tvec = ro - v0;
+                float u = dot(tvec, pvec) * inv_det;
+                if (!(u < 0.0f || u > 1.0f)) {
+                  V3 qvec = cross(tvec, e1);
+                  float v = dot(rd, qvec) * inv_det;
+                  if (!(v < 0.0f || u + v > 1.0f)) {
+                    float t = dot(e2, qvec) * inv_det;
+                    if (t > P.tmin && t < tbest) { tbest = t; hit_slot = i; hit_kind = 2; }
+                  }
+                }
+              }
+            }
+          }
+          if (sp > 0) {
+            sp--;
+            cur = (sp < kStackLds) ? lds_stack[sp * kBlock + tid] : ovf_stack[sp - kStackLds];
+          } else {
+            cur = kDone;
+          }
+        }
+      }
+
+      // ---- (3) shade (rows a6, a8) ------------------------------------------------
+      V3 L = mk(0.f, 0.f, 0.f);
+      bool path_end = false;
+      if (hit_kind == 0) {
+        float t = 0.5f * (rd.y + 1.0f);
+        float a = 1.0f - t;
+        V3 sky = mk(P.sky_bottom[0] * a + P.sky_top[0] * t, P.sky_bottom[1] * a + P.sky_top[1] * t,
+                    P.sky_bottom[2] * a + P.sky_top[2] * t);
+        L = thr * sky;
+        if (bounce == 0 && sample == 0) first_id = RTGPU_NO_HIT;
+        path_end = true;
+      } else {
+        V3 p = ro + rd * tbest;
+        V3 n;
+        uint32_t prim, mat;
+        if (hit_kind == 1) {
+          float4 s = P.sphs[hit_slot];
+          uint2 meta = P.sph_meta[hit_slot];
+          float inv_r = 1.0f / s.w;
+          n = (p - mk(s.x, s.y, s.z)) * inv_r;
+          prim = meta.x;
+          mat = meta.y;
+        } else {
+          const float4 *tp = P.tris + (size_t)hit_slot * 3u;
+          float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
+          n = normalize(cross(mk(t1.x, t1.y, t1.z), mk(t2.x, t2.y, t2.z)));
+          prim = __float_as_uint(t0.w);
+          mat = __float_as_uint(t1.w);
+        }
+        if (bounce == 0 && sample == 0) first_id = prim;
+        float dn = dot(rd, n);
+        bool front = dn < 0.0f;
+        if (!front) n = neg(n);
+
+        float4 m0 = P.mats[mat * 2u], m1 = P.mats[mat * 2u + 1u];
+        V3 albedo = mk(m0.x, m0.y, m0.z);
+        float param = m0.w;
+        uint32_t mtype = __float_as_uint(m1.x);
+        if (STATS) n_scat++;
+        V3 nd = n;
+        bool absorbed = false;
+        if (mtype == RTGPU_MAT_LAMBERTIAN) {
+          V3 ruv = random_unit_vector(rng);
+          V3 sd = n + ruv;
+          if (__builtin_fabsf(sd.x) < 1e-8f && __builtin_fabsf(sd.y) < 1e-8f && __builtin_fabsf(sd.z) < 1e-8f)
+            sd = n;
+          nd = normalize(sd);
+        } else if (mtype == RTGPU_MAT_METAL) {
+          V3 rf = normalize(reflect(rd, n));
+          if (param > 0.0f) {
+            V3 ruv = random_unit_vector(rng);
+            rf = rf + ruv * param;
+          }
+          if (!(dot(rf, n) > 0.0f)) absorbed = true;
+          else nd = normalize(rf);
+        } else {
+          float ri = front ? 1.0f / param : param;
+          float cos_t = fmin_(-dot(rd, n), 1.0f);
+          float sin_t = __builtin_sqrtf(1.0f - cos_t * cos_t);
+          bool cannot = ri * sin_t > 1.0f;
+          float r0 = (1.0f - ri) / (1.0f + ri);
+          r0 = r0 * r0;
+          float xx = 1.0f - cos_t;
+          float x2 = xx * xx;
+          float x5 = x2 * x2 * xx;
+          float refl = r0 + (1.0f - r0) * x5;
+          float u = rng.u01();
+          V3 sd;
+          if (cannot || refl > u) {
+            sd = reflect(rd, n);
+          } else {
+            V3 perp = (rd + n * cos_t) * ri;
+            float par = -__builtin_sqrtf(__builtin_fabsf(1.0f - dot(perp, perp)));
+            sd = perp + n * par;
+          }
+          nd = normalize(sd);
+        }
+        if (absorbed) {
+          path_end = true;
+        } else {
+          thr = thr * albedo;
+          ro = p;
+          rd = nd;
+          bounce++;
+          if (bounce >= P.max_depth) path_end = true;  // depth exhausted: L stays 0
+        }
+      }
+      if (path_end) {
+        sum = sum + L;
+        sample++;
+        alive = false;
+      }
+    }
+  }
+
+  // ---- counters: one atomic per wave and counter --------------------------------
+  n_paths = wave_sum(n_paths);
+  n_rays = wave_sum(n_rays);
+  if (lane == 0) {
+    atomicAdd(&P.counters[1], n_paths);
+    atomicAdd(&P.counters[2], n_rays);
+  }
+  if (STATS) {
+    n_nodes = wave_sum(n_nodes);
+    n_tris = wave_sum(n_tris);
+    n_sphs = wave_sum(n_sphs);
+    n_scat = wave_sum(n_scat);
+    if (lane == 0) {
+      atomicAdd(&P.counters[3], n_nodes);
+      atomicAdd(&P.counters[4], n_tris);
+      atomicAdd(&P.counters[5], n_sphs);
+      atomicAdd(&P.counters[6], n_scat);
+    }
+  }
+}
+
+// accum (float4 sums) -> 0xRRGGBBAA (row a8; packing per shaders.hlsl:18-25)
+__global__ __launch_bounds__(256) void resolve_kernel(const float4 *accum, uint32_t *out, uint64_t n) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    float4 a = accum[i];
+    uint32_t px = 0xFFu;
+    if (a.w > 0.0f) {
+      float c[3] = {a.x, a.y, a.z};
+      uint32_t ch[3];
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        float v = __builtin_sqrtf(fmax_(c[k] / a.w, 0.0f));
+        v = fmin_(v, 0.999f);
+        ch[k] = (uint32_t)(256.0f * v);
+      }
+      px = (ch[0] << 24) | (ch[1] << 16) | (ch[2] << 8) | 0xFFu;
+    }
+    out[i] = px;
+  }
+}
+
+// gathered compact tile buffers (rank-major, each `stride_px` pixels) -> image
+template <typename T>
+__global__ __launch_bounds__(256) void untile_kernel(const T *gathered, T *image, uint32_t width,
+                                                      uint32_t height, uint32_t ts_log2,
+                                                      uint32_t tiles_x, uint32_t world,
+                                                      uint64_t stride_px) {
+  uint64_t n = (uint64_t)width * height;
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t step = (uint64_t)gridDim.x * blockDim.x;
+  uint32_t mask = (1u << ts_log2) - 1u;
+  for (; i < n; i += step) {
+    uint32_t y = (uint32_t)(i / width), x = (uint32_t)(i - (uint64_t)y * width);
+    uint32_t tile = (y >> ts_log2) * tiles_x + (x >> ts_log2);
+    uint32_t rank = tile % world, j = tile / world;
+    uint64_t src = (uint64_t)rank * stride_px + ((uint64_t)j << (2u * ts_log2)) +
+                   ((uint64_t)(y & mask) << ts_log2) + (x & mask);
+    image[i] = gathered[src];
+  }
+}
+
+}  // namespace
+
+// =============================== C ABI ===========================================
+
+struct rtgpu_ctx {
+  int device = 0;
+  std::string err;
+  bool have_scene = false;
+  rtgpu_flat_scene host{};
+  void *d_nodes = nullptr, *d_tris = nullptr, *d_sphs = nullptr, *d_sph_meta = nullptr,
+       *d_mats = nullptr;
+  unsigned long long *d_counters = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool timed = false;
+  int num_cus = 0;
+  int blocks_per_cu[2] = {0, 0};
+  // grow-only staging for the host-pointer entry points
+  void *d_accum = nullptr;  size_t d_accum_bytes = 0;
+  void *d_ids = nullptr;    size_t d_ids_bytes = 0;
+};
+
+namespace {
+
+bool hip_fail(rtgpu_ctx *ctx, hipError_t e, const char *what) {
+  if (e == hipSuccess) return false;
+  ctx->err = std::string(what) + ": " + hipGetErrorString(e);
+  return true;
+}
+#define HIP_TRY(ctx, call)                         \
+  do {                                             \
+    if (hip_fail((ctx), (call), #call)) return 2;  \
+  } while (0)
+
+void free_scene_device(rtgpu_ctx *ctx) {
+  (void)hipFree(ctx->d_nodes);  (void)hipFree(ctx->d_tris);  (void)hipFree(ctx->d_sphs);
+  (void)hipFree(ctx->d_sph_meta);  (void)hipFree(ctx->d_mats);
+  ctx->d_nodes = ctx->d_tris = ctx->d_sphs = ctx->d_sph_meta = ctx->d_mats = nullptr;
+  rtgpu::free_flat_scene(&ctx->host);
+  ctx->have_scene = false;
+}
+
+int upload(rtgpu_ctx *ctx, void **dst, const void *src, size_t bytes) {
+  bytes = ((bytes + 63) / 64) * 64;
+  if (bytes == 0) bytes = 64;
+  HIP_TRY(ctx, hipMalloc(dst, bytes));
+  HIP_TRY(ctx, hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+  return 0;
+}
+
+int check_settings(rtgpu_ctx *ctx, const rtgpu_camera *cam, const rtgpu_settings *s,
+                   uint32_t *ts_log2_out) {
+  if (!cam || !s) { ctx->err = "camera or settings is NULL"; return 1; }
+  if (!ctx->have_scene) { ctx->err = "no scene uploaded (call rtgpu_upload_scene first)"; return 1; }
+  if (s->width == 0 || s->height == 0 || s->width > 65536u || s->height > 65536u) {
+    ctx->err = "width/height must be in 1..65536"; return 1;
+  }
+  if (s->spp == 0 || s->max_depth == 0) { ctx->err = "spp and max_depth must be >= 1"; return 1; }
+  if (s->world_size == 0 || s->rank >= s->world_size) { ctx->err = "rank/world_size invalid"; return 1; }
+  uint32_t ts = s->tile_size, l = 0;
+  while ((1u << l) < ts && l < 31) l++;
+  if (ts < 8 || ts > 1024 || (1u << l) != ts) { ctx->err = "tile_size must be a power of two in 8..1024"; return 1; }
+  if (!(s->tmin >= 0.0f)) { ctx->err = "tmin must be >= 0"; return 1; }
+  *ts_log2_out = l;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" const char *rtgpu_last_error(const rtgpu_ctx *ctx) {
+  return ctx ? ctx->err.c_str() : rtgpu::global_error();
+}
+
+extern "C" int rtgpu_create(rtgpu_ctx **out, int device_index) {
+  if (!out) return 1;
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    rtgpu::set_global_error(std::string("no HIP device: ") + hipGetErrorString(e));
+    return 2;
+  }
+  if (device_index < 0 || device_index >= n) {
+    rtgpu::set_global_error("device_index out of range");
+    return 1;
+  }
+  rtgpu_ctx *ctx = new rtgpu_ctx();
+  ctx->device = device_index;
+  hipDeviceProp_t prop;
+  if ((e = hipSetDevice(device_index)) != hipSuccess ||
+      (e = hipGetDeviceProperties(&prop, device_index)) != hipSuccess ||
+      (e = hipMalloc((void **)&ctx->d_counters, 64)) != hipSuccess ||
+      (e = hipEventCreate(&ctx->ev0)) != hipSuccess || (e = hipEventCreate(&ctx->ev1)) != hipSuccess) {
+    rtgpu::set_global_error(std::string("rtgpu_create: ") + hipGetErrorString(e));
+    rtgpu_destroy(ctx);
+    return 2;
+  }
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    rtgpu::set_global_error(std::string("rtgpu is built for gfx950 only, device is ") + prop.gcnArchName);
+    rtgpu_destroy(ctx);
+    return 2;
+  }
+  ctx->num_cus = prop.multiProcessorCount;
+  int b0 = 0, b1 = 0;
+  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b0, trace_kernel<false>, kBlock, 0);
+  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b1, trace_kernel<true>, kBlock, 0);
+  ctx->blocks_per_cu[0] = b0 > 0 ? b0 : 1;
+  ctx->blocks_per_cu[1] = b1 > 0 ? b1 : 1;
+  *out = ctx;
+  return 0;
+}
+
+extern "C" void rtgpu_destroy(rtgpu_ctx *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  free_scene_device(ctx);
+  (void)hipFree(ctx->d_counters);
+  (void)hipFree(ctx->d_accum);
+  (void)hipFree(ctx->d_ids);
+  if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  delete ctx;
+}
+
+extern "C" int rtgpu_upload_scene(rtgpu_ctx *ctx, const rtgpu_scene_desc *scene) {
+  if (!ctx) return 1;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  free_scene_device(ctx);
+  if (rtgpu::flatten_scene(scene, &ctx->host, ctx->err)) return 1;
+  const rtgpu_flat_scene &h = ctx->host;
+  // the +8 (+16 meta words) zeroed tail records of flatten_scene are uploaded too
+  if (upload(ctx, &ctx->d_nodes, h.nodes, h.n_nodes * sizeof(rtgpu_node)) ||
+      upload(ctx, &ctx->d_tris, h.tris, (h.n_tris + 8) * sizeof(rtgpu_tri)) ||
+      upload(ctx, &ctx->d_sphs, h.spheres, (h.n_spheres + 8) * sizeof(rtgpu_sph)) ||
+      upload(ctx, &ctx->d_sph_meta, h.sphere_meta, (h.n_spheres * 2 + 16) * sizeof(uint32_t)) ||
+      upload(ctx, &ctx->d_mats, h.materials, h.n_materials * sizeof(rtgpu_material))) {
+    std::string keep = ctx->err;
+    free_scene_device(ctx);
+    ctx->err = keep;
+    return 2;
+  }
+  ctx->have_scene = true;
+  return 0;
+}
+
+extern "C" int rtgpu_get_flat_scene(const rtgpu_ctx *ctx, rtgpu_flat_scene *out) {
+  if (!ctx || !out || !ctx->have_scene) return 1;
+  *out = ctx->host;
+  return 0;
+}
+
+extern "C" int rtgpu_render_device(rtgpu_ctx *ctx, const rtgpu_camera *cam, const rtgpu_settings *s,
+                                   void *d_accum_rgba, void *d_prim_id, void *stream_,
+                                   rtgpu_stats *stats) {
+  if (!ctx) return 1;
+  uint32_t ts_log2 = 0;
+  if (check_settings(ctx, cam, s, &ts_log2)) return 1;
+  if (!d_accum_rgba) { ctx->err = "accum output pointer is NULL"; return 1; }
+  hipStream_t stream = (hipStream_t)stream_;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+  rtgpu::TileGrid g = rtgpu::tile_grid(s->width, s->height, s->tile_size);
+  uint64_t local_tiles = rtgpu::rank_tiles(g.n_tiles, s->rank, s->world_size);
+  uint64_t n_items = local_tiles << (2 * ts_log2);
+  if (n_items >= 0xFFFFFFFFull) { ctx->err = "image too large for one launch (>= 2^32 work items)"; return 1; }
+
+  KParams P;
+  std::memset(&P, 0, sizeof(P));
+  P.nodes = (const float4 *)ctx->d_nodes;
+  P.tris = (const float4 *)ctx->d_tris;
+  P.sphs = (const float4 *)ctx->d_sphs;
+  P.sph_meta = (const uint2 *)ctx->d_sph_meta;
+  P.mats = (const float4 *)ctx->d_mats;
+  P.accum = (float4 *)d_accum_rgba;
+  P.prim_id = (uint32_t *)d_prim_id;
+  P.counters = ctx->d_counters;
+  for (int k = 0; k < 3; k++) {
+    P.cam_origin[k] = cam->origin[k]; P.cam_ll[k] = cam->lower_left[k];
+    P.cam_hor[k] = cam->horizontal[k]; P.cam_ver[k] = cam->vertical[k];
+    P.cam_u[k] = cam->u[k]; P.cam_v[k] = cam->v[k];
+    P.sky_bottom[k] = s->sky_bottom[k]; P.sky_top[k] = s->sky_top[k];
+  }
+  P.lens_radius = cam->lens_radius;
+  P.inv_w = 1.0f / (float)s->width;   // IEEE division on the host, as the oracle does
+  P.inv_h = 1.0f / (float)s->height;
+  P.tmin = s->tmin;
+  P.width = s->width; P.height = s->height; P.spp = s->spp; P.sample_offset = s->sample_offset;
+  P.max_depth = s->max_depth; P.seed = s->seed;
+  P.ts_log2 = ts_log2; P.tiles_x = g.tiles_x; P.rank = s->rank; P.world = s->world_size;
+  P.n_items = (uint32_t)n_items; P.flags = s->flags;
+
+  bool want_stats = (s->flags & RTGPU_FLAG_STATS) != 0;
+  HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 64, stream));
+  ctx->timed = false;
+  if (n_items > 0) {
+    uint64_t want = (n_items + kBlock - 1) / kBlock;
+    uint64_t cap = (uint64_t)ctx->num_cus * (uint64_t)ctx->blocks_per_cu[want_stats ? 1 : 0];
+    unsigned grid = (unsigned)(want < cap ? want : cap);
+    HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
+    if (want_stats) hipLaunchKernelGGL(trace_kernel<true>, dim3(grid), dim3(kBlock), 0, stream, P);
+    else            hipLaunchKernelGGL(trace_kernel<false>, dim3(grid), dim3(kBlock), 0, stream, P);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev1, stream));
+    ctx->timed = true;
+  }
+  if (stats) {
+    unsigned long long c[8];
+    HIP_TRY(ctx, hipStreamSynchronize(stream));
+    HIP_TRY(ctx, hipMemcpy(c, ctx->d_counters, sizeof(c), hipMemcpyDeviceToHost));
+    stats->paths = c[1]; stats->rays = c[2]; stats->nodes = c[3];
+    stats->tri_tests = c[4]; stats->sphere_tests = c[5]; stats->scatters = c[6];
+  }
+  return 0;
+}
+
+extern "C" int rtgpu_last_kernel_ms(rtgpu_ctx *ctx, float *ms) {
+  if (!ctx || !ms) return 1;
+  if (!ctx->timed) { ctx->err = "no timed kernel launch on this context yet"; return 1; }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
+  HIP_TRY(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+  return 0;
+}
+
+namespace {
+int ensure(rtgpu_ctx *ctx, void **p, size_t *have, size_t want) {
+  if (*have >= want) return 0;
+  (void)hipFree(*p);
+  *p = nullptr;
+  *have = 0;
+  HIP_TRY(ctx, hipMalloc(p, want));
+  *have = want;
+  return 0;
+}
+}  // namespace
+
+extern "C" int rtgpu_render(rtgpu_ctx *ctx, const rtgpu_camera *cam, const rtgpu_settings *s,
+                            float *accum_rgba, uint32_t *prim_id, rtgpu_stats *stats) {
+  if (!ctx) return 1;
+  uint32_t ts_log2 = 0;
+  if (check_settings(ctx, cam, s, &ts_log2)) return 1;
+  if (!accum_rgba) { ctx->err = "accum output pointer is NULL"; return 1; }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  uint64_t n_px = (s->flags & RTGPU_FLAG_COMPACT)
+                      ? rtgpu_compact_pixels(s->width, s->height, s->tile_size, s->rank, s->world_size)
+                      : (uint64_t)s->width * s->height;
+  if (n_px == 0) return 0;
+  if (ensure(ctx, &ctx->d_accum, &ctx->d_accum_bytes, n_px * 16)) return 2;
+  if (prim_id && ensure(ctx, &ctx->d_ids, &ctx->d_ids_bytes, n_px * 4)) return 2;
+  if (s->flags & RTGPU_FLAG_ACCUMULATE)
+    HIP_TRY(ctx, hipMemcpy(ctx->d_accum, accum_rgba, n_px * 16, hipMemcpyHostToDevice));
+  else
+    HIP_TRY(ctx, hipMemset(ctx->d_accum, 0, n_px * 16));
+  if (prim_id) HIP_TRY(ctx, hipMemset(ctx->d_ids, 0xFF, n_px * 4));
+  int rc = rtgpu_render_device(ctx, cam, s, ctx->d_accum, prim_id ? ctx->d_ids : nullptr, nullptr, stats);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  HIP_TRY(ctx, hipMemcpy(accum_rgba, ctx->d_accum, n_px * 16, hipMemcpyDeviceToHost));
+  if (prim_id) HIP_TRY(ctx, hipMemcpy(prim_id, ctx->d_ids, n_px * 4, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+extern "C" int rtgpu_resolve_rgba8_device(rtgpu_ctx *ctx, const void *d_accum_rgba, void *d_rgba8,
+                                          uint64_t n_pixels, void *stream) {
+  if (!ctx) return 1;
+  if (!d_accum_rgba || !d_rgba8) { ctx->err = "resolve: NULL pointer"; return 1; }
+  if (n_pixels == 0) return 0;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  uint64_t blocks = (n_pixels + 255) / 256;
+  unsigned grid = (unsigned)(blocks < 2048 ? blocks : 2048);
+  hipLaunchKernelGGL(resolve_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                     (const float4 *)d_accum_rgba, (uint32_t *)d_rgba8, n_pixels);
+  HIP_TRY(ctx, hipGetLastError());
+  return 0;
+}
+
+extern "C" int rtgpu_resolve_rgba8(rtgpu_ctx *ctx, const float *accum_rgba, uint32_t *rgba8,
+                                   uint64_t n_pixels) {
+  if (!ctx) return 1;
+  if (!accum_rgba || !rgba8) { ctx->err = "resolve: NULL pointer"; return 1; }
+  if (n_pixels == 0) return 0;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (ensure(ctx, &ctx->d_accum, &ctx->d_accum_bytes, n_pixels * 16)) return 2;
+  if (ensure(ctx, &ctx->d_ids, &ctx->d_ids_bytes, n_pixels * 4)) return 2;
+  HIP_TRY(ctx, hipMemcpy(ctx->d_accum, accum_rgba, n_pixels * 16, hipMemcpyHostToDevice));
+  int rc = rtgpu_resolve_rgba8_device(ctx, ctx->d_accum, ctx->d_ids, n_pixels, nullptr);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  HIP_TRY(ctx, hipMemcpy(rgba8, ctx->d_ids, n_pixels * 4, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+extern "C" int rtgpu_untile_device(rtgpu_ctx *ctx, const void *d_gathered, void *d_image,
+                                   uint32_t width, uint32_t height, uint32_t tile_size,
+                                   uint32_t world_size, uint32_t elem_bytes, void *stream) {
+  if (!ctx) return 1;
+  if (!d_gathered || !d_image) { ctx->err = "untile: NULL pointer"; return 1; }
+  uint32_t l = 0;
+  while ((1u << l) < tile_size && l < 31) l++;
+  if (tile_size < 8 || (1u << l) != tile_size || world_size == 0 || width == 0 || height == 0) {
+    ctx->err = "untile: bad tile_size/world_size/size"; return 1;
+  }
+  if (elem_bytes != 16 && elem_bytes != 4) { ctx->err = "untile: elem_bytes must be 16 or 4"; return 1; }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  rtgpu::TileGrid g = rtgpu::tile_grid(width, height, tile_size);
+  uint64_t stride_px = rtgpu_compact_pixels(width, height, tile_size, 0, world_size);
+  uint64_t n = (uint64_t)width * height;
+  uint64_t blocks = (n + 255) / 256;
+  unsigned grid = (unsigned)(blocks < 4096 ? blocks : 4096);
+  if (elem_bytes == 16)
+    hipLaunchKernelGGL(untile_kernel<float4>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                       (const float4 *)d_gathered, (float4 *)d_image, width, height, l, g.tiles_x,
+                       world_size, stride_px);
+  else
+    hipLaunchKernelGGL(untile_kernel<uint32_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                       (const uint32_t *)d_gathered, (uint32_t *)d_image, width, height, l, g.tiles_x,
+                       world_size, stride_px);
+  HIP_TRY(ctx, hipGetLastError());
+  return 0;
+}
