@@ -57,6 +57,8 @@ def load():
     lib.rto_resolve_rgba8.restype = None
     lib.rto_validate_bvh.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
     lib.rto_has_openmp.restype = C.c_int
+    lib.rto_debug_max_stack.argtypes = [C.c_int]
+    lib.rto_debug_max_stack.restype = C.c_int
     return lib
 
 

@@ -267,6 +267,13 @@ static inline void leaf_intersect(const scene_t *sc, const ray_t *r, uint32_t re
 /* Closest hit by ordered stack traversal of the flattened BVH2 (row a3):
  * one node fetch tests both children; both hit -> nearer first (tie: child 0),
  * the other is pushed; a popped entry is visited without any re-test. */
+static int g_max_stack; /* debug high-water mark (benign race under OpenMP) */
+RTO_API int rto_debug_max_stack(int reset) {
+  int v = g_max_stack;
+  if (reset) g_max_stack = 0;
+  return v;
+}
+
 static hit_t intersect_bvh(const scene_t *sc, const ray_t *r, float tmin, counters_t *cn) {
   hit_t best = {0, 0, 0, INFINITY};
   uint32_t stack[RTGPU_MAX_TREE_DEPTH + 2];
@@ -284,6 +291,7 @@ static hit_t intersect_bvh(const scene_t *sc, const ray_t *r, float tmin, counte
       if (h0 && h1) {
         if (tn1 < tn0) { stack[sp++] = n->child0; cur = n->child1; }
         else           { stack[sp++] = n->child1; cur = n->child0; }
+        if (sp > g_max_stack) g_max_stack = sp;
         continue;
       }
       if (h0) { cur = n->child0; continue; }

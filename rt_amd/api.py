@@ -15,6 +15,29 @@ if not os.path.exists(LIB_PATH):
         "rt_amd has no CPU fallback."
     )
 
+
+
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm wheels bundle their own libamdhip64 (soname libamdhip64.so.7,
+    file name libamdhip64.so).  A process that loads BOTH the system runtime
+    (through librtgpu.so) and torch's copy ends up with two HIP/HSA runtimes and
+    the second one finds no GPU.  Loading torch's copy first makes the dynamic
+    loader resolve librtgpu.so's NEEDED libamdhip64.so.7 to it by soname, so the
+    two share one runtime whichever is imported first.  Without torch installed
+    the system runtime (/opt/rocm/lib) is used, as for any C/C++ caller."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    p = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(p):
+        C.CDLL(p, mode=C.RTLD_GLOBAL)
+
+
+_share_hip_runtime_with_torch()
 lib = C.CDLL(LIB_PATH)
 
 FLAG_ACCUMULATE = 1

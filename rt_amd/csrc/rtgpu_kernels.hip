@@ -31,7 +31,7 @@
 namespace {
 
 constexpr int      kBlock      = 256;
-constexpr int      kStackLds   = 24;   // entries per lane in LDS
+constexpr int      kStackLds   = 16;   // entries per lane in LDS
 constexpr int      kStackOvf   = RTGPU_MAX_TREE_DEPTH + 2 - kStackLds;  // rest, in scratch
 constexpr uint32_t kDone       = 0xFFFFFFFFu;  // == RTGPU_REF_EMPTY, has the leaf bit
 

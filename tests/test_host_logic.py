@@ -1,0 +1,129 @@
+"""Host-side logic of the product library that needs no GPU: BVH builder and
+flattener, builtin scenes, camera reduction, tile bookkeeping."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from util import bits, fnv1a_words, golden_json, make_scene
+
+
+def test_flatten_is_deterministic_and_pinned(ra):
+    scene, _ = ra.Scene.builtin(0)
+    a, b = ra.FlatScene.build(scene), ra.FlatScene.build(scene)
+    assert np.array_equal(a.nodes_u32, b.nodes_u32) and np.array_equal(a.tris_u32, b.tris_u32)
+    assert np.array_equal(a.spheres_f32.view(np.uint32), b.spheres_f32.view(np.uint32))
+    g = golden_json("checksums.json")["flat_s0"]
+    assert (a.c.n_nodes, a.c.max_depth, a.c.n_spheres, a.c.n_tris) == (
+        g["n_nodes"], g["max_depth"], g["n_spheres"], g["n_tris"])
+    assert fnv1a_words(a.nodes_u32) == g["nodes_fnv"]
+
+
+@pytest.mark.parametrize("kind,param", [(0, 0), (1, 3), (1, 6), (2, 3)])
+def test_bvh_is_structurally_valid(ra, oracle, kind, param):
+    scene, _ = ra.Scene.builtin(kind, param=param)
+    fs = ra.FlatScene.build(scene)
+    rc, depth = oracle.validate_bvh(fs.c)
+    assert rc == 0, f"validator code {rc}"
+    assert depth == fs.c.max_depth <= 62
+    assert fs.c.n_tris == len(scene.triangles) and fs.c.n_spheres == len(scene.spheres)
+    # leaf-ordered arrays are a permutation of the input primitives
+    if len(scene.spheres):
+        ids = np.sort(fs.sphere_meta[:, 0])
+        assert np.array_equal(ids, np.arange(len(scene.spheres)))
+    if len(scene.triangles):
+        ids = np.sort(fs.tris_u32[:, 3])
+        assert np.array_equal(ids, len(scene.spheres) + np.arange(len(scene.triangles)))
+
+
+def test_builtin_scene_sizes(ra):
+    s0, _ = ra.Scene.builtin(0)
+    assert 450 <= s0.n_prims <= 490 and len(s0.triangles) == 2
+    assert s0.spheres[0]["radius"] == 1000.0          # prim id 0 = ground sphere
+    s1, _ = ra.Scene.builtin(1, param=4)
+    assert len(s1.triangles) == 20 * 4 ** 4 + 2
+    s2, _ = ra.Scene.builtin(2, param=2)
+    assert len(s2.triangles) == 8 * 20 * 4 ** 2
+    assert set(np.unique(s2.materials["type"])) == {0, 1, 2}
+    # same seed -> same bytes; other seed -> other layout
+    s0b, _ = ra.Scene.builtin(0)
+    s0c, _ = ra.Scene.builtin(0, seed=5)
+    assert s0.spheres.tobytes() == s0b.spheres.tobytes() and s0.spheres.tobytes() != s0c.spheres.tobytes()
+
+
+def test_icosphere_is_watertight(ra):
+    """Shared edges are bit-identical from both triangles (no vertex cache needed)."""
+    s1, _ = ra.Scene.builtin(1, param=3)
+    t = s1.triangles[:-2]
+    v = np.stack([t["v0"], t["v1"], t["v2"]], 1).view(np.uint32)          # [n,3,3] bit patterns
+    edges = {}
+    for tri in v:
+        for a, b in ((0, 1), (1, 2), (2, 0)):
+            key = frozenset((tri[a].tobytes(), tri[b].tobytes()))
+            edges[key] = edges.get(key, 0) + 1
+    assert set(edges.values()) == {2}
+
+
+def test_flatten_rejects_bad_input(ra):
+    L = ra.lib
+    from rt_amd.api import FlatSceneC
+    out = FlatSceneC()
+    bad_mat = make_scene(ra, spheres=[(0, 0, 0, 1, 3)], materials=[(0, .5, .5, .5, 0)])
+    assert L.rtgpu_flatten_scene_host(C.byref(bad_mat.desc), C.byref(out)) != 0
+    assert b"material" in L.rtgpu_last_error(None)
+    nan = make_scene(ra, spheres=[(float("nan"), 0, 0, 1, 0)], materials=[(0, .5, .5, .5, 0)])
+    assert L.rtgpu_flatten_scene_host(C.byref(nan.desc), C.byref(out)) != 0
+    neg = make_scene(ra, spheres=[(0, 0, 0, -1, 0)], materials=[(0, .5, .5, .5, 0)])
+    assert L.rtgpu_flatten_scene_host(C.byref(neg.desc), C.byref(out)) != 0
+    nomat = make_scene(ra, spheres=[(0, 0, 0, 1, 0)])
+    assert L.rtgpu_flatten_scene_host(C.byref(nomat.desc), C.byref(out)) != 0
+    inf_tri = make_scene(ra, triangles=[((0, 0, 0), (1, 0, 0), (0, float("inf"), 0), 0)],
+                         materials=[(0, .5, .5, .5, 0)])
+    assert L.rtgpu_flatten_scene_host(C.byref(inf_tri.desc), C.byref(out)) != 0
+
+
+def test_flatten_tiny_scenes(ra, oracle):
+    empty = ra.FlatScene.build(make_scene(ra))
+    assert empty.c.n_nodes == 1 and empty.nodes_u32[0, 12] == 0xFFFFFFFF == empty.nodes_u32[0, 13]
+    one = ra.FlatScene.build(make_scene(ra, spheres=[(0, 0, 0, 1, 0)], materials=[(0, .5, .5, .5, 0)]))
+    assert one.c.n_nodes == 1 and one.nodes_u32[0, 13] == 0xFFFFFFFF
+    assert one.nodes_u32[0, 12] == 0x80000000 | 0x40000000  # leaf, sphere, count 1, first 0
+    assert oracle.validate_bvh(one.c)[0] == 0
+    # 64 coincident spheres: SAH cannot split them, median split must
+    same = ra.FlatScene.build(make_scene(ra, spheres=[(0, 0, 0, 1, 0)] * 64, materials=[(0, .5, .5, .5, 0)]))
+    assert oracle.validate_bvh(same.c)[0] == 0
+    # mixed leaf candidates are split by type
+    mixed = ra.FlatScene.build(make_scene(
+        ra, spheres=[(0, 0, 0, 1, 0), (0.1, 0, 0, 1, 0)],
+        triangles=[((0, 0, 0), (1, 0, 0), (0, 1, 0), 0)], materials=[(0, .5, .5, .5, 0)]))
+    assert oracle.validate_bvh(mixed.c)[0] == 0
+
+
+def test_camera_look_at(ra):
+    cam = ra.look_at((13, 2, 3), (0, 0, 0), (0, 1, 0), vfov=20.0, aspect=16 / 9, aperture=0.1, focus_dist=10.0)
+    frm, at, up = np.array([13, 2, 3.0]), np.zeros(3), np.array([0, 1.0, 0])
+    h = np.tan(np.radians(np.float64(np.float32(20.0))) / 2)
+    w = (frm - at) / np.linalg.norm(frm - at)
+    u = np.cross(up, w); u /= np.linalg.norm(u)
+    v = np.cross(w, u)
+    hor, ver = 10.0 * np.float64(np.float32(16 / 9)) * 2 * h * u, 10.0 * 2 * h * v
+    np.testing.assert_allclose(np.array(cam.horizontal), hor, rtol=2e-7)
+    np.testing.assert_allclose(np.array(cam.vertical), ver, rtol=2e-7, atol=1e-7)
+    np.testing.assert_allclose(np.array(cam.lower_left), frm - hor / 2 - ver / 2 - 10.0 * w, rtol=2e-7)
+    assert list(cam.origin) == [13.0, 2.0, 3.0] and cam.lens_radius == np.float32(0.05)
+
+
+def test_tile_bookkeeping(ra):
+    from rt_amd import dist
+    for (w, h, ts, world) in ((1920, 1080, 64, 1), (1920, 1080, 64, 8), (100, 70, 16, 3), (64, 64, 64, 2), (8, 8, 8, 4)):
+        tiles = ((w + ts - 1) // ts) * ((h + ts - 1) // ts)
+        per = [ra.compact_pixels(w, h, ts, r, world) // (ts * ts) for r in range(world)]
+        assert sum(per) == tiles and max(per) - min(per) <= 1 and per[0] == max(per)
+        idx = dist.tile_index_map(w, h, ts, world)
+        assert len(np.unique(idx)) == w * h             # injective
+        assert idx.max() < world * dist.padded_pixels(w, h, ts, world)
+        img = np.arange(w * h * 2, dtype=np.float32).reshape(h, w, 2)
+        parts = [dist.compact_from_image(img, w, h, ts, r, world) for r in range(world)]
+        back = dist.untile_host(np.concatenate(parts), w, h, ts, world)
+        assert np.array_equal(back, img)
+    assert ra.compact_pixels(64, 64, 64, 5, 4) == 0     # rank >= world

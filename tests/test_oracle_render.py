@@ -1,0 +1,145 @@
+"""The oracle's frame loop against its golden fixtures and against itself
+(BVH vs exhaustive search, threads, crops, tiles, progressive frames)."""
+import numpy as np
+import pytest
+
+from util import GOLDEN, assert_bit_equal, bits, fnv1a_words, golden_json, make_scene
+
+
+@pytest.fixture(scope="module")
+def s0_small(ra):
+    scene, cam = ra.Scene.builtin(0, aspect=64 / 36)
+    return scene, cam, ra.FlatScene.build(scene)
+
+
+def test_golden_crop(ra, oracle, s0_small):
+    _, cam, fs = s0_small
+    g = np.load(f"{GOLDEN}/s0_64x36.npz")
+    chk = golden_json("checksums.json")
+    acc, ids, stats = oracle.render(fs.c, cam, ra.default_settings(64, 36, spp=1, max_depth=8))
+    assert np.array_equal(ids, g["ids"])
+    assert np.array_equal(bits(acc), g["accum_1spp"])
+    assert stats == chk["s0_64x36_stats_1spp"]
+    acc4, _, stats4 = oracle.render(fs.c, cam, ra.default_settings(64, 36, spp=4, max_depth=8))
+    assert np.array_equal(bits(acc4), g["accum_4spp"])
+    assert stats4 == chk["s0_64x36_stats_4spp"]
+
+
+@pytest.mark.parametrize("depth", [1, 8])
+def test_c1_frame_checksums(ra, oracle, depth):
+    """BASELINE.json configs[0]: default scene, 1280x720, 1 spp, CPU path."""
+    scene, cam = ra.Scene.builtin(0, aspect=1280 / 720)
+    fs = ra.FlatScene.build(scene)
+    acc, ids, stats = oracle.render(fs.c, cam, ra.default_settings(1280, 720, spp=1, max_depth=depth), threads=8)
+    g = golden_json("checksums.json")[f"c1_1280x720_depth{depth}"]
+    assert fnv1a_words(ids) == g["ids_fnv"]
+    assert fnv1a_words(bits(acc)) == g["accum_fnv"]
+    assert stats == g["stats"]
+    if depth == 1:  # RTIOW: a path that exhausts its depth contributes nothing
+        hit = ids != ra.NO_HIT
+        assert np.all(acc[hit][:, :3] == 0) and np.all(acc[~hit][:, :3] > 0)
+
+
+@pytest.mark.parametrize("kind,param", [(0, 0), (1, 3), (2, 2)])
+def test_bvh_equals_exhaustive_search(ra, oracle, kind, param):
+    """Builder + traversal vs testing every primitive (no BVH): same closest hit
+    for every segment of every path, so identical images and identical paths."""
+    scene, cam = ra.Scene.builtin(kind, param=param, aspect=48 / 27)
+    fs = ra.FlatScene.build(scene)
+    st = ra.default_settings(48, 27, spp=2, max_depth=6)
+    a, ia, sa = oracle.render(fs.c, cam, st)
+    b, ib, sb = oracle.render(fs.c, cam, st, brute_force=True)
+    assert np.array_equal(ia, ib)
+    assert_bit_equal(a, b, "bvh vs brute force")
+    assert (sa["rays"], sa["scatters"]) == (sb["rays"], sb["scatters"])
+    assert sb["nodes"] == 0 and sa["nodes"] > 0
+
+
+def test_threads_crop_and_tiles_do_not_change_pixels(ra, oracle, s0_small):
+    _, cam, fs = s0_small
+    st = ra.default_settings(64, 36, spp=2, max_depth=8, tile_size=16)
+    full, ids, stats = oracle.render(fs.c, cam, st)
+    par, ids_p, stats_p = oracle.render(fs.c, cam, st, threads=5)
+    assert_bit_equal(full, par, "threads")
+    assert stats == stats_p
+    crop, ids_c, _ = oracle.render(fs.c, cam, st, crop=(10, 5, 30, 20))
+    assert_bit_equal(crop[5:20, 10:30], full[5:20, 10:30], "crop")
+    assert np.all(crop[:5] == 0) and np.all(ids_c[20:] == ra.NO_HIT)
+    # union of the ranks' tiles == the full frame, for any world size
+    for world in (2, 3):
+        acc = np.zeros_like(full)
+        total_rays = 0
+        for r in range(world):
+            st_r = ra.default_settings(64, 36, spp=2, max_depth=8, tile_size=16, rank=r, world_size=world)
+            acc, _, s = oracle.render(fs.c, cam, st_r, accum=acc)
+            total_rays += s["rays"]
+        assert_bit_equal(acc, full, f"world {world}")
+        assert total_rays == stats["rays"]
+
+
+def test_progressive_frames(ra, oracle, s0_small):
+    """Two 2-spp frames with ACCUMULATE and sample_offset see the same samples as
+    one 4-spp frame (sum order differs, so compare to a tolerance) and w = 4."""
+    _, cam, fs = s0_small
+    one, _, _ = oracle.render(fs.c, cam, ra.default_settings(64, 36, spp=4, max_depth=8))
+    a, _, _ = oracle.render(fs.c, cam, ra.default_settings(64, 36, spp=2, max_depth=8))
+    b, _, _ = oracle.render(fs.c, cam, ra.default_settings(64, 36, spp=2, max_depth=8, sample_offset=2,
+                                                           flags=ra.FLAG_ACCUMULATE), accum=a.copy())
+    assert np.all(b[..., 3] == 4.0)
+    np.testing.assert_allclose(b, one, rtol=1e-6, atol=1e-6)
+    # ...and exactly: frame sums added in order
+    f2, _, _ = oracle.render(fs.c, cam, ra.default_settings(64, 36, spp=2, max_depth=8, sample_offset=2))
+    assert_bit_equal(b[..., :3], a[..., :3] + f2[..., :3], "accumulate")
+
+
+def test_sky_only_and_materials(ra, oracle):
+    cam = ra.look_at((0, 0, 5), (0, 0, 0), vfov=40.0, aspect=1.0)
+    st = ra.default_settings(32, 32, spp=4, max_depth=8)
+    # empty scene: every path is the sky gradient, in [bottom, top] per channel
+    fs = ra.FlatScene.build(make_scene(ra))  # keep it alive: .c borrows its memory
+    acc, ids, stats = oracle.render(fs.c, cam, st)
+    assert np.all(ids == ra.NO_HIT) and stats["rays"] == stats["paths"] == 32 * 32 * 4
+    mean = acc[..., :3] / 4
+    assert np.all(mean[..., 2] == 1.0) and np.all((mean[..., 0] >= 0.5) & (mean[..., 0] <= 1.0))
+    assert np.all(np.diff(mean[:, 16, 0]) < 0)   # row 0 is the bottom: whiter below, bluer above
+    # white-furnace style bounds: albedo-1 surfaces never create energy
+    for mat in ((0, 1, 1, 1, 0), (1, 1, 1, 1, 0.0), (1, 1, 1, 1, 0.5), (2, 1, 1, 1, 1.5)):
+        sc = make_scene(ra, spheres=[(0, 0, 0, 1, 0), (0, -101, 0, 100, 0)], materials=[mat])
+        fs = ra.FlatScene.build(sc)
+        acc, ids, _ = oracle.render(fs.c, cam, st)
+        assert (ids == 0).sum() > 100
+        assert np.all(acc[..., :3] / 4 <= 1.0 + 1e-6) and np.all(np.isfinite(acc))
+    # a mirror (metal, fuzz 0) facing the camera reflects the sky exactly once: 2 segments per hit path
+    sc = make_scene(ra, triangles=[((-50, -50, 0), (50, -50, 0), (0, 50, 0), 0)], materials=[(1, 1, 1, 1, 0)])
+    fs = ra.FlatScene.build(sc)
+    acc, ids, stats = oracle.render(fs.c, cam, st)
+    assert np.all(ids == 0) and stats["rays"] == 2 * stats["paths"] and stats["scatters"] == stats["paths"]
+
+
+def test_thin_lens_changes_rays_but_not_determinism(ra, oracle):
+    scene, cam = ra.Scene.builtin(0, aspect=1.0)
+    lens = ra.look_at((13, 2, 3), (0, 0, 0), vfov=20.0, aspect=1.0, aperture=0.1, focus_dist=10.0)
+    fs = ra.FlatScene.build(scene)
+    st = ra.default_settings(32, 32, spp=2, max_depth=8)
+    a, _, _ = oracle.render(fs.c, cam, st)
+    b, _, _ = oracle.render(fs.c, lens, st)
+    c, _, _ = oracle.render(fs.c, lens, st, threads=3)
+    assert not np.array_equal(a, b)
+    assert_bit_equal(b, c, "lens determinism")
+
+
+def test_deep_tree_traversal(ra, oracle):
+    """Geometric chain of spheres -> a BVH much deeper than the kernel's LDS
+    short stack (16 entries); BVH and exhaustive search still agree."""
+    sph = [(float(3.0 ** i), 0.0, 0.0, float(0.25 * 3.0 ** i), 0) for i in range(-16, 40)]
+    sc = make_scene(ra, spheres=sph, materials=[(0, .5, .5, .5, 0)])
+    fs = ra.FlatScene.build(sc)
+    assert fs.c.max_depth >= 28 and oracle.validate_bvh(fs.c)[0] == 0
+    cam = ra.look_at((-1e-9, 0.0, 0.0), (1, 0, 0), vfov=30.0, aspect=1.0)
+    st = ra.default_settings(16, 16, spp=1, max_depth=3)
+    oracle.lib.rto_debug_max_stack(1)
+    a, ia, _ = oracle.render(fs.c, cam, st)
+    assert oracle.lib.rto_debug_max_stack(1) > 20, "scene does not overflow the kernel's LDS short stack"
+    b, ib, _ = oracle.render(fs.c, cam, st, brute_force=True)
+    assert np.array_equal(ia, ib) and (ia != ra.NO_HIT).any()
+    assert_bit_equal(a, b, "deep tree")
