@@ -97,7 +97,8 @@ typedef struct rtgpu_camera {
 enum {
   RTGPU_FLAG_ACCUMULATE = 1u, /* out = in + frame (progressive), else out = frame */
   RTGPU_FLAG_COMPACT    = 2u, /* write this rank's tiles as a compact tile list   */
-  RTGPU_FLAG_STATS      = 4u  /* run the instrumented variant (node/prim counters) */
+  RTGPU_FLAG_STATS      = 4u, /* run the instrumented variant (node/prim counters) */
+  RTGPU_FLAG_PROFILE    = 8u  /* STATS + per-wave trip counters (rtgpu_profile_counters) */
 };
 
 typedef struct rtgpu_settings {
@@ -177,6 +178,14 @@ int  rtgpu_render_device(rtgpu_ctx *ctx, const rtgpu_camera *cam, const rtgpu_se
 /* Duration of the trace kernel of the last render call on this context,
  * measured with HIP events on the stream the kernel ran on.  Synchronises. */
 int  rtgpu_last_kernel_ms(rtgpu_ctx *ctx, float *ms);
+
+/* Diagnostics: raw counters of the last launch on this context.  out[0] queue
+ * head, [1..6] as rtgpu_stats, and with RTGPU_FLAG_PROFILE [7..15] = per-WAVE
+ * execution counts {outer iterations, shade blocks, lanes in shade blocks,
+ * camera-ray blocks, node steps, sphere tests, triangle tests, traversal
+ * rounds, lanes in traversal rounds}: lane totals / (64 x wave counts) is the
+ * SIMD lane utilisation of each section.  Synchronises the device. */
+int  rtgpu_profile_counters(rtgpu_ctx *ctx, uint64_t out[16]);
 
 /* accum (float4 sums) -> 0xRRGGBBAA, gamma 2, like RTIOW's write_color.
  * Packing per run_tree/data/shaders/shaders.hlsl:18-25. Device pointers. */

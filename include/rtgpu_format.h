@@ -27,7 +27,9 @@ typedef struct rtgpu_node {
  *   bit 31 = 1 : leaf; bit 30 = 1 sphere / 0 triangle;
  *                bits 27..29 = count-1 (1..8 primitives, one type per leaf);
  *                bits 0..26  = first index into the leaf-ordered array
- *   0xFFFFFFFF : empty child (its box is inverted and never hit)            */
+ *   0xFFFFFFFF : empty child (only in scenes of < 2 primitives); its box sits
+ *                at +inf on every axis and the closest-hit distance starts at
+ *                FLT_MAX, so the slab test can never pass for it              */
 #define RTGPU_REF_LEAF    0x80000000u
 #define RTGPU_REF_SPHERE  0x40000000u
 #define RTGPU_REF_EMPTY   0xFFFFFFFFu

@@ -231,6 +231,8 @@ typedef struct {
   uint64_t n_nodes, n_tris, n_sphs, n_mats;
 } scene_t;
 
+#define T_MAX 3.402823466e+38f /* FLT_MAX: initial closest-hit distance */
+
 typedef struct {
   int hit;
   int is_sphere;
@@ -275,7 +277,7 @@ RTO_API int rto_debug_max_stack(int reset) {
 }
 
 static hit_t intersect_bvh(const scene_t *sc, const ray_t *r, float tmin, counters_t *cn) {
-  hit_t best = {0, 0, 0, INFINITY};
+  hit_t best = {0, 0, 0, T_MAX};
   uint32_t stack[RTGPU_MAX_TREE_DEPTH + 2];
   int sp = 0;
   uint32_t cur = 0; /* root */
@@ -286,8 +288,11 @@ static hit_t intersect_bvh(const scene_t *sc, const ray_t *r, float tmin, counte
       const rtgpu_node *n = &sc->nodes[cur];
       float tn0, tn1;
       cn->nodes++;
-      int h0 = slab(r, n->lo0, n->hi0, tmin, best.t, &tn0) && n->child0 != RTGPU_REF_EMPTY;
-      int h1 = slab(r, n->lo1, n->hi1, tmin, best.t, &tn1) && n->child1 != RTGPU_REF_EMPTY;
+      /* an empty child (scenes of < 2 primitives) has its box at +inf: its slab
+       * interval is [+inf,+inf] or [-inf,-inf] per axis and best.t <= FLT_MAX,
+       * so it never passes */
+      int h0 = slab(r, n->lo0, n->hi0, tmin, best.t, &tn0);
+      int h1 = slab(r, n->lo1, n->hi1, tmin, best.t, &tn1);
       if (h0 && h1) {
         if (tn1 < tn0) { stack[sp++] = n->child0; cur = n->child1; }
         else           { stack[sp++] = n->child1; cur = n->child0; }
@@ -307,7 +312,7 @@ static hit_t intersect_bvh(const scene_t *sc, const ray_t *r, float tmin, counte
  * Same per-primitive tests; visiting order = leaf-array order (spheres, then
  * triangles), so only exact-t ties between primitives can differ from the BVH. */
 static hit_t intersect_brute(const scene_t *sc, const ray_t *r, float tmin, counters_t *cn) {
-  hit_t best = {0, 0, 0, INFINITY};
+  hit_t best = {0, 0, 0, T_MAX};
   for (uint64_t i = 0; i < sc->n_sphs; i++) {
     float t;
     cn->sphere_tests++;

@@ -24,6 +24,7 @@ from .api import (  # noqa: F401
     FLAG_ACCUMULATE,
     FLAG_COMPACT,
     FLAG_STATS,
+    FLAG_PROFILE,
     NO_HIT,
     SCENE_SEED,
 )

@@ -43,6 +43,7 @@ lib = C.CDLL(LIB_PATH)
 FLAG_ACCUMULATE = 1
 FLAG_COMPACT = 2
 FLAG_STATS = 4
+FLAG_PROFILE = 8
 NO_HIT = 0xFFFFFFFF
 SCENE_SEED = 0x52545F31  # "RT_1" 
 
@@ -134,6 +135,7 @@ lib.rtgpu_flat_scene_free.restype = None
 lib.rtgpu_render.argtypes = [C.c_void_p, _P(Camera), _P(Settings), C.c_void_p, C.c_void_p, _P(Stats)]
 lib.rtgpu_render_device.argtypes = [
     C.c_void_p, _P(Camera), _P(Settings), C.c_void_p, C.c_void_p, C.c_void_p, _P(Stats)]
+lib.rtgpu_profile_counters.argtypes = [C.c_void_p, _P(C.c_uint64)]
 lib.rtgpu_last_kernel_ms.argtypes = [C.c_void_p, _P(C.c_float)]
 lib.rtgpu_resolve_rgba8_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
 lib.rtgpu_resolve_rgba8.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
@@ -324,6 +326,11 @@ class Context:
         self._check(lib.rtgpu_render_device(
             self._h, C.byref(cam), C.byref(settings), accum_ptr, ids_ptr, stream,
             C.byref(stats) if stats is not None else None))
+
+    def profile_counters(self):
+        out = (C.c_uint64 * 16)()
+        self._check(lib.rtgpu_profile_counters(self._h, out))
+        return [int(v) for v in out]
 
     def kernel_ms(self):
         ms = C.c_float()

@@ -306,7 +306,10 @@ int flatten_scene(const rtgpu_scene_desc *scene, rtgpu_flat_scene *out, std::str
   B.sphs.reserve(scene->n_spheres);
   B.sph_meta.reserve(scene->n_spheres * 2);
 
-  const float inv_lo = 1e30f, inv_hi = -1e30f;  // inverted box: never hit
+  // Empty child: a box at +inf.  Its slab interval is [+inf,+inf] or [-inf,-inf]
+  // on every axis, and the closest-hit distance starts at FLT_MAX, so it can
+  // never pass tnear <= tfar (include/rtgpu_format.h).
+  const float inv_lo = INFINITY, inv_hi = INFINITY;
   if (n <= 1) {
     rtgpu_node root;
     std::memset(&root, 0, sizeof(root));
@@ -324,6 +327,10 @@ int flatten_scene(const rtgpu_scene_desc *scene, rtgpu_flat_scene *out, std::str
     Box bounds;
     uint32_t r = B.build(0, n, 0, bounds);
     if (r != 0) { err = "internal: root is not node 0"; return 1; }
+  }
+  if (B.nodes.size() * sizeof(rtgpu_node) >= (1ull << 32) || B.tris.size() * sizeof(rtgpu_tri) >= (1ull << 32)) {
+    err = "scene too large: node or triangle buffer would reach 4 GiB (the kernel uses 32-bit offsets)";
+    return 1;
   }
   if (B.max_depth > RTGPU_MAX_TREE_DEPTH) {
     err = "internal: BVH deeper than RTGPU_MAX_TREE_DEPTH";

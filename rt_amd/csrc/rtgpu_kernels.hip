@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -31,9 +32,11 @@
 namespace {
 
 constexpr int      kBlock      = 256;
-constexpr int      kStackLds   = 16;   // entries per lane in LDS
-constexpr int      kStackOvf   = RTGPU_MAX_TREE_DEPTH + 2 - kStackLds;  // rest, in scratch
+constexpr int      kStackLds   = 32;   // entries per lane in LDS (32 KiB per 256-thread block)
+constexpr int      kStackOvf   = RTGPU_MAX_TREE_DEPTH + 2;  // global overflow entries per lane (covers stack_lds >= 2)
 constexpr uint32_t kDone       = 0xFFFFFFFFu;  // == RTGPU_REF_EMPTY, has the leaf bit
+constexpr unsigned kChunk      = 64;   // work items drawn per queue atomic (one 8x8 pixel block)
+constexpr float    kTMax       = 3.402823466e+38f;  // FLT_MAX: initial closest-hit distance
 
 struct KParams {
   const float4 *nodes;
@@ -43,6 +46,7 @@ struct KParams {
   const float4 *mats;
   float4       *accum;
   uint32_t     *prim_id;
+  uint32_t     *ovf_stack;  // [kStackOvf][grid threads], see struct Stack
   unsigned long long *counters;  // [0] queue head, [1] paths, [2] rays, [3] nodes, [4] tris, [5] sphs, [6] scatters
   float cam_origin[3], cam_ll[3], cam_hor[3], cam_ver[3], cam_u[3], cam_v[3];
   float lens_radius;
@@ -50,6 +54,7 @@ struct KParams {
   float sky_bottom[3], sky_top[3];
   uint32_t width, height, spp, sample_offset, max_depth, seed;
   uint32_t ts_log2, tiles_x, rank, world, n_items, flags;
+  uint32_t stack_lds, stack_lds_only;
 };
 
 struct V3 { float x, y, z; };
@@ -116,10 +121,52 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
   return v;
 }
 
-template <bool STATS>
+// Traversal stack: up to kStackLds entries per lane in LDS, laid out
+// [entry][thread] (lane-consecutive dwords: conflict-free ds_read/ds_write_b32);
+// deeper entries go to a per-lane slice of a global overflow buffer laid out the
+// same way.  Entry 0 holds the sentinel kDone, so pop() needs no emptiness test:
+// popping the sentinel ends the traversal.  A stack never grows past the tree
+// depth + 1, which the host knows: when that fits in LDS the kernel takes the
+// `lds_only` path (a wave-uniform branch) and every push/pop is a bare
+// ds_write/ds_read.
+struct Stack {
+  uint32_t *lds;        // &lds_stack[tid]
+  uint32_t *ovf;        // &ovf[global thread]
+  uint32_t ovf_stride;  // threads in the grid
+  int lds_entries;      // entries of the LDS part in use (<= kStackLds)
+  bool lds_only;        // tree depth + 1 < lds_entries: the overflow part is unreachable
+  int sp;               // next free entry; >= 1 while a traversal is running
+  __device__ __forceinline__ void reset() { sp = 1; }
+  __device__ __forceinline__ void push(uint32_t v) {
+    if (lds_only || sp < lds_entries) lds[sp * kBlock] = v;
+    else ovf[(size_t)(sp - lds_entries) * ovf_stride] = v;
+    sp++;
+  }
+  __device__ __forceinline__ uint32_t pop() {
+    sp--;
+    uint32_t v;
+    if (lds_only || sp < lds_entries) v = lds[sp * kBlock];
+    else v = ovf[(size_t)(sp - lds_entries) * ovf_stride];
+    return v;
+  }
+};
+
+// REFILL: leave the traversal loop as soon as fewer than REFILL lanes of the
+// wave are still traversing (and at least one has finished), so that finished
+// lanes shade and start their next ray instead of idling behind the longest
+// traversal of the wave; unfinished lanes keep their traversal state in
+// registers and resume.  REFILL = 0 waits for every lane (plain while-while).
+// Profile build only (STATS == 2): count one per WAVE for the code it guards,
+// charged to the lowest active lane, so that sum(lane counts) / (64 * wave count)
+// is the SIMD lane utilisation of that section.
+__device__ __forceinline__ void wave_tick(unsigned lane, unsigned long long &c) {
+  unsigned long long m = __ballot(1);
+  if (lane == (unsigned)__ffsll((long long)m) - 1u) c++;
+}
+
+template <int STATS, int REFILL>
 __global__ __launch_bounds__(kBlock) void trace_kernel(const KParams P) {
   __shared__ uint32_t lds_stack[kStackLds * kBlock];
-  uint32_t ovf_stack[kStackOvf];
   const unsigned tid = threadIdx.x;
   const unsigned lane = lane_id();
 
@@ -134,189 +181,32 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const KParams P) {
   V3 sum = mk(0.f, 0.f, 0.f), thr = mk(1.f, 1.f, 1.f), ro = mk(0.f, 0.f, 0.f), rd = mk(0.f, 0.f, 1.f);
   Rng rng = {0u, 0u};
   unsigned long long n_paths = 0, n_rays = 0, n_nodes = 0, n_tris = 0, n_sphs = 0, n_scat = 0;
+  unsigned long long w_outer = 0, w_shade = 0, l_shade = 0, w_gen = 0, w_node = 0, w_sph = 0, w_tri = 0,
+                     w_trav = 0, l_trav = 0;
+  // traversal state (survives an early exit from the traversal loop)
+  V3 inv = mk(1.f, 1.f, 1.f), noi = mk(0.f, 0.f, 0.f);
+  float tbest = kTMax;
+  uint32_t hit_slot = 0, cur = kDone;
+  int hit_kind = 0;  // 0 none, 1 sphere, 2 triangle
+  unsigned pool_next = 0, pool_end = 0;  // wave-local slice of the work queue (wave-uniform)
+  Stack stk;
+  stk.lds = lds_stack + tid;
+  stk.ovf_stride = gridDim.x * kBlock;
+  stk.ovf = P.ovf_stack + (size_t)blockIdx.x * kBlock + tid;
+  stk.sp = 1;
+  stk.lds_entries = (int)P.stack_lds;
+  stk.lds_only = P.stack_lds_only != 0u;
+  lds_stack[tid] = kDone;  // sentinel under every lane's stack (never overwritten)
+  const float tmin = P.tmin;
+  const char *const nodes_base = (const char *)P.nodes;
+  const char *const tris_base = (const char *)P.tris;
+  const char *const sphs_base = (const char *)P.sphs;
 
   for (;;) {
-    // ---- (1) lanes without a path in flight: next sample, or next pixel ------
-    bool need_pixel = !alive && !done && (!have_pixel || sample >= P.spp);
-    if (need_pixel && have_pixel) {
-      if (pixel_valid) {
-        float4 o = make_float4(sum.x, sum.y, sum.z, (float)P.spp);
-        if (P.flags & RTGPU_FLAG_ACCUMULATE) {
-          float4 in = P.accum[out_index];
-          o.x = in.x + o.x; o.y = in.y + o.y; o.z = in.z + o.z; o.w = in.w + o.w;
-        }
-        P.accum[out_index] = o;
-        if (P.prim_id) P.prim_id[out_index] = first_id;
-      }
-      have_pixel = false;
-    }
-    unsigned long long need_mask = __ballot(need_pixel);
-    if (need_mask != 0ull) {  // wave-uniform
-      unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(need_mask >> 32),
-                                                __builtin_amdgcn_mbcnt_lo((unsigned)need_mask, 0u));
-      unsigned leader = (unsigned)__ffsll((long long)need_mask) - 1u;
-      unsigned long long base = 0;
-      if (lane == leader)
-        base = atomicAdd(&P.counters[0], (unsigned long long)__popcll(need_mask));
-      base = __shfl(base, (int)leader, 64);
-      if (need_pixel) {
-        unsigned long long item = base + rank;
-        if (item >= (unsigned long long)P.n_items) {
-          done = true;
-        } else {
-          // item -> (local tile, 8x8 block in tile, pixel in block): lanes of a
-          // wave that fetch together trace one 8x8 pixel block
-          uint32_t it = (uint32_t)item;
-          uint32_t k = it & (ts * ts - 1u), j = it >> (2u * P.ts_log2);
-          uint32_t blk = k >> 6, within = k & 63u;
-          uint32_t tx = ((blk & ((1u << blocks_per_row_log2) - 1u)) << 3) + (within & 7u);
-          uint32_t ty = ((blk >> blocks_per_row_log2) << 3) + (within >> 3);
-          uint32_t tile = P.rank + j * P.world;
-          uint32_t tile_y = tile / P.tiles_x, tile_x = tile - tile_y * P.tiles_x;
-          px = (tile_x << P.ts_log2) + tx;
-          py = (tile_y << P.ts_log2) + ty;
-          pixel_valid = px < P.width && py < P.height;
-          out_index = (P.flags & RTGPU_FLAG_COMPACT) ? (j << (2u * P.ts_log2)) + (ty << P.ts_log2) + tx
-                                                      : py * P.width + px;
-          have_pixel = true;
-          sample = pixel_valid ? 0u : P.spp;  // out-of-image pixel: nothing to trace
-          sum = mk(0.f, 0.f, 0.f);
-          first_id = RTGPU_NO_HIT;
-        }
-      }
-    }
-    if (!alive && !done && have_pixel && sample < P.spp) {
-      // ---- camera ray (row a1) ----
-      rng.key = pcg((P.sample_offset + sample) ^ pcg((py * P.width + px) ^ pcg(P.seed)));
-      rng.ctr = 0;
-      float jx = rng.u01(), jy = rng.u01();
-      float sx = ((float)px + jx) * P.inv_w;
-      float sy = ((float)py + jy) * P.inv_h;
-      V3 dir = ((cam_ll + cam_hor * sx) + cam_ver * sy) - cam_o;
-      ro = cam_o;
-      if (P.lens_radius > 0.0f) {
-        float a = 0.0f, b = 0.0f;
-        bool found = false;
-#pragma unroll 1
-        for (int i = 0; i < 8 && !found; i++) {
-          float ta = rng.u01() * 2.0f - 1.0f;
-          float tb = rng.u01() * 2.0f - 1.0f;
-          if (ta * ta + tb * tb < 1.0f) { a = ta; b = tb; found = true; }
-        }
-        float ra = a * P.lens_radius, rb = b * P.lens_radius;
-        V3 off = ld3(P.cam_u) * ra + ld3(P.cam_v) * rb;
-        ro = cam_o + off;
-        dir = dir - off;
-      }
-      rd = normalize(dir);
-      thr = mk(1.f, 1.f, 1.f);
-      bounce = 0;
-      alive = true;
-      n_paths++;
-    }
-    if (__ballot(alive) == 0ull) break;  // done implies !alive: the whole wave is dry
-
-    if (alive) {
-      // ---- (2) closest hit: ordered while-while traversal (rows a3-a5) --------
-      const V3 inv = mk(1.0f / clamp_dir(rd.x), 1.0f / clamp_dir(rd.y), 1.0f / clamp_dir(rd.z));
-      const V3 noi = mk(-(ro.x * inv.x), -(ro.y * inv.y), -(ro.z * inv.z));
-      float tbest = __builtin_inff();
-      uint32_t hit_slot = 0;
-      int hit_kind = 0;  // 0 none, 1 sphere, 2 triangle
-      uint32_t cur = 0;  // root
-      int sp = 0;
-      n_rays++;
-
-      while (cur != kDone) {
-        while (!(cur & RTGPU_REF_LEAF)) {
-          const float4 *n = P.nodes + (size_t)cur * 4u;
-          float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
-          if (STATS) n_nodes++;
-          // child 0: lo (q0.x q0.y q0.z) hi (q0.w q1.x q1.y); child 1: lo (q1.z q1.w q2.x) hi (q2.y q2.z q2.w)
-          float a0x = __builtin_fmaf(q0.x, inv.x, noi.x), a1x = __builtin_fmaf(q0.w, inv.x, noi.x);
-          float a0y = __builtin_fmaf(q0.y, inv.y, noi.y), a1y = __builtin_fmaf(q1.x, inv.y, noi.y);
-          float a0z = __builtin_fmaf(q0.z, inv.z, noi.z), a1z = __builtin_fmaf(q1.y, inv.z, noi.z);
-          float tn0 = fmax_(fmax_(fmin_(a0x, a1x), fmin_(a0y, a1y)), fmax_(fmin_(a0z, a1z), P.tmin));
-          float tf0 = fmin_(fmin_(fmax_(a0x, a1x), fmax_(a0y, a1y)), fmin_(fmax_(a0z, a1z), tbest));
-          float b0x = __builtin_fmaf(q1.z, inv.x, noi.x), b1x = __builtin_fmaf(q2.y, inv.x, noi.x);
-          float b0y = __builtin_fmaf(q1.w, inv.y, noi.y), b1y = __builtin_fmaf(q2.z, inv.y, noi.y);
-          float b0z = __builtin_fmaf(q2.x, inv.z, noi.z), b1z = __builtin_fmaf(q2.w, inv.z, noi.z);
-          float tn1 = fmax_(fmax_(fmin_(b0x, b1x), fmin_(b0y, b1y)), fmax_(fmin_(b0z, b1z), P.tmin));
-          float tf1 = fmin_(fmin_(fmax_(b0x, b1x), fmax_(b0y, b1y)), fmin_(fmax_(b0z, b1z), tbest));
-          uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
-          bool h0 = (tn0 <= tf0) && (c0 != RTGPU_REF_EMPTY);
-          bool h1 = (tn1 <= tf1) && (c1 != RTGPU_REF_EMPTY);
-          if (h0 && h1) {
-            bool swap = tn1 < tn0;
-            uint32_t nearc = swap ? c1 : c0, farc = swap ? c0 : c1;
-            if (sp < kStackLds) lds_stack[sp * kBlock + tid] = farc;
-            else ovf_stack[sp - kStackLds] = farc;
-            sp++;
-            cur = nearc;
-          } else if (h0) {
-            cur = c0;
-          } else if (h1) {
-            cur = c1;
-          } else if (sp > 0) {
-            sp--;
-            cur = (sp < kStackLds) ? lds_stack[sp * kBlock + tid] : ovf_stack[sp - kStackLds];
-          } else {
-            cur = kDone;
-          }
-        }
-        if (cur != kDone) {
-          uint32_t first = RTGPU_REF_FIRST(cur), count = RTGPU_REF_COUNT(cur);
-          if (cur & RTGPU_REF_SPHERE) {
-#pragma unroll 1
-            for (uint32_t i = first; i < first + count; i++) {
-              float4 s = P.sphs[i];
-              if (STATS) n_sphs++;
-              V3 oc = ro - mk(s.x, s.y, s.z);
-              float hb = dot(oc, rd);
-              float cc = dot(oc, oc) - s.w * s.w;
-              float disc = hb * hb - cc;
-              if (!(disc < 0.0f)) {
-                float sq = __builtin_sqrtf(disc);
-                float t = -hb - sq;
-                bool ok = t > P.tmin && t < tbest;
-                if (!ok) { t = -hb + sq; ok = t > P.tmin && t < tbest; }
-                if (ok) { tbest = t; hit_slot = i; hit_kind = 1; }
-              }
-            }
-          } else {
-#pragma unroll 1
-            for (uint32_t i = first; i < first + count; i++) {
-              const float4 *tp = P.tris + (size_t)i * 3u;
-              float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
-              if (STATS) n_tris++;
-              V3 v0 = mk(t0.x, t0.y, t0.z), e1 = mk(t1.x, t1.y, t1.z), e2 = mk(t2.x, t2.y, t2.z);
-              V3 pvec = cross(rd, e2);
-              float det = dot(e1, pvec);
-              if (!(__builtin_fabsf(det) < 1e-30f)) {
-                float inv_det = 1.0f / det;
-                V3 tvec = ro - v0;
-                float u = dot(tvec, pvec) * inv_det;
-                if (!(u < 0.0f || u > 1.0f)) {
-                  V3 qvec = cross(tvec, e1);
-                  float v = dot(rd, qvec) * inv_det;
-                  if (!(v < 0.0f || u + v > 1.0f)) {
-                    float t = dot(e2, qvec) * inv_det;
-                    if (t > P.tmin && t < tbest) { tbest = t; hit_slot = i; hit_kind = 2; }
-                  }
-                }
-              }
-            }
-          }
-          if (sp > 0) {
-            sp--;
-            cur = (sp < kStackLds) ? lds_stack[sp * kBlock + tid] : ovf_stack[sp - kStackLds];
-          } else {
-            cur = kDone;
-          }
-        }
-      }
-
-      // ---- (3) shade (rows a6, a8) ------------------------------------------------
+    // ---- (1) shade the rays whose traversal has finished (rows a6, a8) ----------
+    if (STATS == 2) wave_tick(lane, w_outer);
+    if (alive && cur == kDone) {
+      if (STATS == 2) { wave_tick(lane, w_shade); l_shade++; }
       V3 L = mk(0.f, 0.f, 0.f);
       bool path_end = false;
       if (hit_kind == 0) {
@@ -325,7 +215,6 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const KParams P) {
         V3 sky = mk(P.sky_bottom[0] * a + P.sky_top[0] * t, P.sky_bottom[1] * a + P.sky_top[1] * t,
                     P.sky_bottom[2] * a + P.sky_top[2] * t);
         L = thr * sky;
-        if (bounce == 0 && sample == 0) first_id = RTGPU_NO_HIT;
         path_end = true;
       } else {
         V3 p = ro + rd * tbest;
@@ -355,22 +244,23 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const KParams P) {
         float param = m0.w;
         uint32_t mtype = __float_as_uint(m1.x);
         if (STATS) n_scat++;
-        V3 nd = n;
+        // The three scatter functions share their expensive pieces, so a wave
+        // that holds all three materials runs each piece once: one unit-vector
+        // draw (lambertian, fuzzy metal), one final normalisation.  Per lane the
+        // operations and the RNG draws are exactly the oracle's.
+        const bool is_lamb = mtype == RTGPU_MAT_LAMBERTIAN, is_metal = mtype == RTGPU_MAT_METAL;
+        V3 ruv = mk(0.f, 0.f, 0.f);
+        if (is_lamb || (is_metal && param > 0.0f)) ruv = random_unit_vector(rng);
+        V3 sd;
         bool absorbed = false;
-        if (mtype == RTGPU_MAT_LAMBERTIAN) {
-          V3 ruv = random_unit_vector(rng);
-          V3 sd = n + ruv;
+        if (is_lamb) {
+          sd = n + ruv;
           if (__builtin_fabsf(sd.x) < 1e-8f && __builtin_fabsf(sd.y) < 1e-8f && __builtin_fabsf(sd.z) < 1e-8f)
             sd = n;
-          nd = normalize(sd);
-        } else if (mtype == RTGPU_MAT_METAL) {
-          V3 rf = normalize(reflect(rd, n));
-          if (param > 0.0f) {
-            V3 ruv = random_unit_vector(rng);
-            rf = rf + ruv * param;
-          }
-          if (!(dot(rf, n) > 0.0f)) absorbed = true;
-          else nd = normalize(rf);
+        } else if (is_metal) {
+          sd = normalize(reflect(rd, n));
+          if (param > 0.0f) sd = sd + ruv * param;
+          absorbed = !(dot(sd, n) > 0.0f);
         } else {
           float ri = front ? 1.0f / param : param;
           float cos_t = fmin_(-dot(rd, n), 1.0f);
@@ -383,7 +273,6 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const KParams P) {
           float x5 = x2 * x2 * xx;
           float refl = r0 + (1.0f - r0) * x5;
           float u = rng.u01();
-          V3 sd;
           if (cannot || refl > u) {
             sd = reflect(rd, n);
           } else {
@@ -391,8 +280,8 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const KParams P) {
             float par = -__builtin_sqrtf(__builtin_fabsf(1.0f - dot(perp, perp)));
             sd = perp + n * par;
           }
-          nd = normalize(sd);
         }
+        V3 nd = normalize(sd);
         if (absorbed) {
           path_end = true;
         } else {
@@ -407,6 +296,222 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const KParams P) {
         sum = sum + L;
         sample++;
         alive = false;
+      }
+    }
+
+    // ---- (2) lanes without a path in flight: next sample, or next pixel ---------
+    bool need_pixel = !alive && !done && (!have_pixel || sample >= P.spp);
+    if (need_pixel && have_pixel) {
+      if (pixel_valid) {
+        float4 o = make_float4(sum.x, sum.y, sum.z, (float)P.spp);
+        if (P.flags & RTGPU_FLAG_ACCUMULATE) {
+          float4 in = P.accum[out_index];
+          o.x = in.x + o.x; o.y = in.y + o.y; o.z = in.z + o.z; o.w = in.w + o.w;
+        }
+        P.accum[out_index] = o;
+        if (P.prim_id) P.prim_id[out_index] = first_id;
+      }
+      have_pixel = false;
+    }
+    unsigned long long need_mask = __ballot(need_pixel);
+    if (need_mask != 0ull) {  // wave-uniform
+      // Work queue: the global head is one word, and a returning atomic on one
+      // word saturates near 88 per microsecond chip-wide (MI355X_MICROARCH.md,
+      // row "dequeue") - one atomic per finished pixel made the queue, not the
+      // tracing, the bottleneck of the 1080p frame.  So a wave draws kChunk items
+      // (one 8x8 pixel block) per atomic into a wave-local pool [pool_next,
+      // pool_end) and its lanes take from the pool by their rank among the needy
+      // lanes (ballot + mbcnt prefix): one atomic per 64 pixels.
+      const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(need_mask >> 32),
+                                                      __builtin_amdgcn_mbcnt_lo((unsigned)need_mask, 0u));
+      const unsigned cnt = (unsigned)__builtin_popcountll(need_mask);
+      const unsigned avail = pool_end - pool_next;  // wave-uniform
+      unsigned item_lo = pool_next + rank;
+      if (cnt > avail) {                            // wave-uniform: refill
+        const unsigned leader = (unsigned)__ffsll((long long)need_mask) - 1u;
+        unsigned long long fetched = 0;
+        if (lane == leader) fetched = atomicAdd(&P.counters[0], (unsigned long long)kChunk);
+        fetched = __shfl(fetched, (int)leader, 64);
+        // a head beyond n_items means the queue is dry; clamp so u32 math cannot wrap
+        const unsigned nb = fetched >= (unsigned long long)P.n_items ? P.n_items : (unsigned)fetched;
+        if (rank >= avail) item_lo = nb + (rank - avail);
+        pool_next = nb + (cnt - avail);
+        pool_end = nb + kChunk;
+        if (nb >= P.n_items) { pool_next = P.n_items; pool_end = P.n_items; }
+      } else {
+        pool_next += cnt;
+      }
+      if (need_pixel) {
+        const unsigned item = item_lo;
+        if (item >= P.n_items) {
+          done = true;
+        } else {
+          // item -> (local tile, 8x8 block in tile, pixel in block): lanes of a
+          // wave that fetch together trace one 8x8 pixel block
+          uint32_t it = item;
+          uint32_t k = it & (ts * ts - 1u), j = it >> (2u * P.ts_log2);
+          uint32_t blk = k >> 6, within = k & 63u;
+          uint32_t tx = ((blk & ((1u << blocks_per_row_log2) - 1u)) << 3) + (within & 7u);
+          uint32_t ty = ((blk >> blocks_per_row_log2) << 3) + (within >> 3);
+          uint32_t tile = P.rank + j * P.world;
+          uint32_t tile_y = tile / P.tiles_x, tile_x = tile - tile_y * P.tiles_x;
+          px = (tile_x << P.ts_log2) + tx;
+          py = (tile_y << P.ts_log2) + ty;
+          pixel_valid = px < P.width && py < P.height;
+          out_index = (P.flags & RTGPU_FLAG_COMPACT) ? (j << (2u * P.ts_log2)) + (ty << P.ts_log2) + tx
+                                                      : py * P.width + px;
+          have_pixel = true;
+          sample = pixel_valid ? 0u : P.spp;  // out-of-image pixel: nothing to trace
+          sum = mk(0.f, 0.f, 0.f);
+          first_id = RTGPU_NO_HIT;
+        }
+      }
+    }
+    if (!alive && !done && have_pixel && sample < P.spp) {
+      // ---- camera ray (row a1) ----
+      if (STATS == 2) wave_tick(lane, w_gen);
+      rng.key = pcg((P.sample_offset + sample) ^ pcg((py * P.width + px) ^ pcg(P.seed)));
+      rng.ctr = 0;
+      float jx = rng.u01(), jy = rng.u01();
+      float sx = ((float)px + jx) * P.inv_w;
+      float sy = ((float)py + jy) * P.inv_h;
+      V3 dir = ((cam_ll + cam_hor * sx) + cam_ver * sy) - cam_o;
+      ro = cam_o;
+      if (P.lens_radius > 0.0f) {
+        float a = 0.0f, b = 0.0f;
+        bool found = false;
+#pragma unroll 1
+        for (int i = 0; i < 8 && !found; i++) {
+          float ta = rng.u01() * 2.0f - 1.0f;
+          float tb = rng.u01() * 2.0f - 1.0f;
+          if (ta * ta + tb * tb < 1.0f) { a = ta; b = tb; found = true; }
+        }
+        float ra = a * P.lens_radius, rb = b * P.lens_radius;
+        V3 off = ld3(P.cam_u) * ra + ld3(P.cam_v) * rb;
+        ro = cam_o + off;
+        dir = dir - off;
+      }
+      rd = normalize(dir);
+      thr = mk(1.f, 1.f, 1.f);
+      bounce = 0;
+      alive = true;
+      n_paths++;
+    }
+    if (__ballot(alive) == 0ull) break;  // done implies !alive: the whole wave is dry
+
+    // ---- (3) start the traversal of every new segment --------------------------
+    if (alive && cur == kDone) {
+      inv = mk(1.0f / clamp_dir(rd.x), 1.0f / clamp_dir(rd.y), 1.0f / clamp_dir(rd.z));
+      noi = mk(-(ro.x * inv.x), -(ro.y * inv.y), -(ro.z * inv.z));
+      tbest = kTMax;
+      hit_kind = 0;
+      cur = 0;  // root
+      stk.reset();
+      n_rays++;
+    }
+
+    // ---- (4) closest hit: ordered stack traversal (rows a3-a5) ------------------
+    // Every lane walks its own ray in the oracle's order; what the WAVE executes
+    // next is put to a vote: the step kind (inner node / sphere leaf / triangle
+    // leaf) that most lanes are waiting for runs, the other lanes sit the round
+    // out.  A plain while-while loop ran the node step for as few as one lane
+    // (measured 13-27 % lane utilisation); the vote keeps each step above half
+    // of the lanes that are still traversing.
+    const int n_entry = __popcll(__ballot(cur != kDone));
+    for (;;) {
+      // reference encoding read as a signed int: inner node >= 0; triangle leaf
+      // < -2^30; sphere leaf in [-2^30, -2]; kDone == -1
+      const int icur = (int)cur;
+      const bool trav = icur != -1;
+      const bool at_node = icur >= 0;
+      const bool at_tri = icur < (int)0xC0000000u;
+      const bool at_sph = trav && !at_node && !at_tri;
+      const int n_trav = __builtin_popcountll(__ballot(trav));
+      const int n_node = __builtin_popcountll(__ballot(at_node));
+      const int n_tri = __builtin_popcountll(__ballot(at_tri));
+      const int n_sph = n_trav - n_node - n_tri;
+      if (n_trav == 0 || (n_trav < REFILL && n_trav < n_entry)) break;  // wave-uniform
+      if (STATS == 2) { wave_tick(lane, w_trav); if (trav) l_trav++; }
+      if (n_node >= n_sph && n_node >= n_tri) {
+        if (at_node) {
+          if (STATS == 2) wave_tick(lane, w_node);
+          const float4 *n = (const float4 *)(nodes_base + (cur << 6));  // 32-bit offset: < 4 GiB of nodes
+          float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
+          if (STATS) n_nodes++;
+          // child 0: lo (q0.x q0.y q0.z) hi (q0.w q1.x q1.y); child 1: lo (q1.z q1.w q2.x) hi (q2.y q2.z q2.w)
+          float a0x = __builtin_fmaf(q0.x, inv.x, noi.x), a1x = __builtin_fmaf(q0.w, inv.x, noi.x);
+          float a0y = __builtin_fmaf(q0.y, inv.y, noi.y), a1y = __builtin_fmaf(q1.x, inv.y, noi.y);
+          float a0z = __builtin_fmaf(q0.z, inv.z, noi.z), a1z = __builtin_fmaf(q1.y, inv.z, noi.z);
+          float tn0 = fmax_(fmax_(fmin_(a0x, a1x), fmin_(a0y, a1y)), fmax_(fmin_(a0z, a1z), tmin));
+          float tf0 = fmin_(fmin_(fmax_(a0x, a1x), fmax_(a0y, a1y)), fmin_(fmax_(a0z, a1z), tbest));
+          float b0x = __builtin_fmaf(q1.z, inv.x, noi.x), b1x = __builtin_fmaf(q2.y, inv.x, noi.x);
+          float b0y = __builtin_fmaf(q1.w, inv.y, noi.y), b1y = __builtin_fmaf(q2.z, inv.y, noi.y);
+          float b0z = __builtin_fmaf(q2.x, inv.z, noi.z), b1z = __builtin_fmaf(q2.w, inv.z, noi.z);
+          float tn1 = fmax_(fmax_(fmin_(b0x, b1x), fmin_(b0y, b1y)), fmax_(fmin_(b0z, b1z), tmin));
+          float tf1 = fmin_(fmin_(fmax_(b0x, b1x), fmax_(b0y, b1y)), fmin_(fmax_(b0z, b1z), tbest));
+          uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
+          // an empty child (scenes of < 2 primitives) has its box at +inf and can
+          // never pass: tfar <= tbest <= FLT_MAX < tnear
+          bool h0 = tn0 <= tf0;
+          bool h1 = tn1 <= tf1;
+          // both hit: nearer first (tie: child 0), the other is pushed
+          bool swap = tn1 < tn0;
+          uint32_t near_c = (h0 && !(h1 && swap)) ? c0 : c1;
+          uint32_t far_c = swap ? c0 : c1;
+          if (h0 && h1) stk.push(far_c);
+          if (!(h0 || h1)) near_c = stk.pop();
+          cur = near_c;
+        }
+      } else if (n_sph >= n_tri) {
+        if (at_sph) {
+          uint32_t first = RTGPU_REF_FIRST(cur), count = RTGPU_REF_COUNT(cur);
+#pragma unroll 1
+          for (uint32_t i = first; i < first + count; i++) {
+            float4 s = *(const float4 *)(sphs_base + (i << 4));
+            if (STATS) n_sphs++;
+            if (STATS == 2) wave_tick(lane, w_sph);
+            V3 oc = ro - mk(s.x, s.y, s.z);
+            float hb = dot(oc, rd);
+            float cc = dot(oc, oc) - s.w * s.w;
+            float disc = hb * hb - cc;
+            if (!(disc < 0.0f)) {
+              float sq = __builtin_sqrtf(disc);
+              float t = -hb - sq;
+              bool ok = t > tmin && t < tbest;
+              if (!ok) { t = -hb + sq; ok = t > tmin && t < tbest; }
+              if (ok) { tbest = t; hit_slot = i; hit_kind = 1; }
+            }
+          }
+          cur = stk.pop();
+        }
+      } else {
+        if (at_tri) {
+          uint32_t first = RTGPU_REF_FIRST(cur), count = RTGPU_REF_COUNT(cur);
+#pragma unroll 1
+          for (uint32_t i = first; i < first + count; i++) {
+            const float4 *tp = (const float4 *)(tris_base + i * 48u);  // 32-bit offset: < 4 GiB of triangles
+            float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
+            if (STATS) n_tris++;
+            if (STATS == 2) wave_tick(lane, w_tri);
+            V3 v0 = mk(t0.x, t0.y, t0.z), e1 = mk(t1.x, t1.y, t1.z), e2 = mk(t2.x, t2.y, t2.z);
+            V3 pvec = cross(rd, e2);
+            float det = dot(e1, pvec);
+            if (!(__builtin_fabsf(det) < 1e-30f)) {
+              float inv_det = 1.0f / det;
+              V3 tvec = ro - v0;
+              float u = dot(tvec, pvec) * inv_det;
+              if (!(u < 0.0f || u > 1.0f)) {
+                V3 qvec = cross(tvec, e1);
+                float v = dot(rd, qvec) * inv_det;
+                if (!(v < 0.0f || u + v > 1.0f)) {
+                  float t = dot(e2, qvec) * inv_det;
+                  if (t > tmin && t < tbest) { tbest = t; hit_slot = i; hit_kind = 2; }
+                }
+              }
+            }
+          }
+          cur = stk.pop();
+        }
       }
     }
   }
@@ -428,6 +533,14 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const KParams P) {
       atomicAdd(&P.counters[4], n_tris);
       atomicAdd(&P.counters[5], n_sphs);
       atomicAdd(&P.counters[6], n_scat);
+    }
+  }
+  if (STATS == 2) {
+    unsigned long long v[9] = {w_outer, w_shade, l_shade, w_gen, w_node, w_sph, w_tri, w_trav, l_trav};
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      unsigned long long t = wave_sum(v[i]);
+      if (lane == 0) atomicAdd(&P.counters[7 + i], t);
     }
   }
 }
@@ -489,13 +602,30 @@ struct rtgpu_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
   int num_cus = 0;
+  int variant = 0;              // index into kVariants (refill threshold), see rtgpu_create
+  int stack_lds = kStackLds;    // LDS stack entries in use (RTGPU_STACK_LDS shrinks it for tests)
   int blocks_per_cu[2] = {0, 0};
+  uint32_t *d_ovf = nullptr;    // traversal-stack overflow, sized for the largest grid
+  size_t ovf_threads = 0;
   // grow-only staging for the host-pointer entry points
   void *d_accum = nullptr;  size_t d_accum_bytes = 0;
   void *d_ids = nullptr;    size_t d_ids_bytes = 0;
 };
 
 namespace {
+
+// Kernel variants: {refill threshold} x {plain, instrumented}.  One source, one
+// code path; the threshold only changes WHEN finished lanes are refilled, never
+// what a path computes.  RTGPU_REFILL (0/16/32/48) selects it for experiments.
+using KernelFn = void (*)(const KParams);
+struct Variant { int refill; KernelFn plain, stats, profile; };
+const Variant kVariants[] = {
+    {0, trace_kernel<0, 0>, trace_kernel<1, 0>, trace_kernel<2, 0>},
+    {16, trace_kernel<0, 16>, trace_kernel<1, 16>, trace_kernel<2, 16>},
+    {32, trace_kernel<0, 32>, trace_kernel<1, 32>, trace_kernel<2, 32>},
+    {48, trace_kernel<0, 48>, trace_kernel<1, 48>, trace_kernel<2, 48>},
+};
+constexpr int kDefaultVariant = 1;  // refill below 16 traversing lanes (measured best on C2/C3/C5)
 
 bool hip_fail(rtgpu_ctx *ctx, hipError_t e, const char *what) {
   if (e == hipSuccess) return false;
@@ -564,7 +694,7 @@ extern "C" int rtgpu_create(rtgpu_ctx **out, int device_index) {
   hipDeviceProp_t prop;
   if ((e = hipSetDevice(device_index)) != hipSuccess ||
       (e = hipGetDeviceProperties(&prop, device_index)) != hipSuccess ||
-      (e = hipMalloc((void **)&ctx->d_counters, 64)) != hipSuccess ||
+      (e = hipMalloc((void **)&ctx->d_counters, 128)) != hipSuccess ||
       (e = hipEventCreate(&ctx->ev0)) != hipSuccess || (e = hipEventCreate(&ctx->ev1)) != hipSuccess) {
     rtgpu::set_global_error(std::string("rtgpu_create: ") + hipGetErrorString(e));
     rtgpu_destroy(ctx);
@@ -576,11 +706,33 @@ extern "C" int rtgpu_create(rtgpu_ctx **out, int device_index) {
     return 2;
   }
   ctx->num_cus = prop.multiProcessorCount;
+  ctx->variant = kDefaultVariant;
+  if (const char *env = std::getenv("RTGPU_REFILL")) {
+    int want = std::atoi(env);
+    for (int i = 0; i < (int)(sizeof(kVariants) / sizeof(kVariants[0])); i++)
+      if (kVariants[i].refill == want) ctx->variant = i;
+  }
+  if (const char *env = std::getenv("RTGPU_STACK_LDS")) {
+    int want = std::atoi(env);
+    if (want >= 2 && want <= kStackLds) ctx->stack_lds = want;
+  }
   int b0 = 0, b1 = 0;
-  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b0, trace_kernel<false>, kBlock, 0);
-  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b1, trace_kernel<true>, kBlock, 0);
+  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b0, kVariants[ctx->variant].plain, kBlock, 0);
+  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b1, kVariants[ctx->variant].stats, kBlock, 0);
+  if (const char *env = std::getenv("RTGPU_BLOCKS_PER_CU")) {
+    int want = std::atoi(env);
+    if (want > 0 && want < b0) b0 = want;
+    if (want > 0 && want < b1) b1 = want;
+  }
   ctx->blocks_per_cu[0] = b0 > 0 ? b0 : 1;
   ctx->blocks_per_cu[1] = b1 > 0 ? b1 : 1;
+  ctx->ovf_threads = (size_t)ctx->num_cus * (size_t)(b0 > b1 ? b0 : b1) * kBlock;
+  if (ctx->ovf_threads == 0) ctx->ovf_threads = kBlock;
+  if ((e = hipMalloc((void **)&ctx->d_ovf, ctx->ovf_threads * kStackOvf * sizeof(uint32_t))) != hipSuccess) {
+    rtgpu::set_global_error(std::string("rtgpu_create: overflow stack: ") + hipGetErrorString(e));
+    rtgpu_destroy(ctx);
+    return 2;
+  }
   *out = ctx;
   return 0;
 }
@@ -590,6 +742,7 @@ extern "C" void rtgpu_destroy(rtgpu_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   free_scene_device(ctx);
   (void)hipFree(ctx->d_counters);
+  (void)hipFree(ctx->d_ovf);
   (void)hipFree(ctx->d_accum);
   (void)hipFree(ctx->d_ids);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -650,6 +803,7 @@ extern "C" int rtgpu_render_device(rtgpu_ctx *ctx, const rtgpu_camera *cam, cons
   P.accum = (float4 *)d_accum_rgba;
   P.prim_id = (uint32_t *)d_prim_id;
   P.counters = ctx->d_counters;
+  P.ovf_stack = ctx->d_ovf;
   for (int k = 0; k < 3; k++) {
     P.cam_origin[k] = cam->origin[k]; P.cam_ll[k] = cam->lower_left[k];
     P.cam_hor[k] = cam->horizontal[k]; P.cam_ver[k] = cam->vertical[k];
@@ -664,17 +818,22 @@ extern "C" int rtgpu_render_device(rtgpu_ctx *ctx, const rtgpu_camera *cam, cons
   P.max_depth = s->max_depth; P.seed = s->seed;
   P.ts_log2 = ts_log2; P.tiles_x = g.tiles_x; P.rank = s->rank; P.world = s->world_size;
   P.n_items = (uint32_t)n_items; P.flags = s->flags;
+  P.stack_lds = (uint32_t)ctx->stack_lds;
+  // pushes never exceed the tree depth; +1 for the sentinel
+  P.stack_lds_only = (ctx->host.max_depth + 1u < (uint32_t)ctx->stack_lds) ? 1u : 0u;
 
-  bool want_stats = (s->flags & RTGPU_FLAG_STATS) != 0;
-  HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 64, stream));
+  bool want_stats = (s->flags & (RTGPU_FLAG_STATS | RTGPU_FLAG_PROFILE)) != 0;
+  HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 128, stream));
   ctx->timed = false;
   if (n_items > 0) {
     uint64_t want = (n_items + kBlock - 1) / kBlock;
     uint64_t cap = (uint64_t)ctx->num_cus * (uint64_t)ctx->blocks_per_cu[want_stats ? 1 : 0];
     unsigned grid = (unsigned)(want < cap ? want : cap);
+    if ((size_t)grid * kBlock > ctx->ovf_threads) { ctx->err = "internal: grid exceeds the overflow stack"; return 2; }
+    const Variant &var = kVariants[ctx->variant];
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
-    if (want_stats) hipLaunchKernelGGL(trace_kernel<true>, dim3(grid), dim3(kBlock), 0, stream, P);
-    else            hipLaunchKernelGGL(trace_kernel<false>, dim3(grid), dim3(kBlock), 0, stream, P);
+    KernelFn fn = (s->flags & RTGPU_FLAG_PROFILE) ? var.profile : want_stats ? var.stats : var.plain;
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), 0, stream, P);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev1, stream));
     ctx->timed = true;
@@ -686,6 +845,14 @@ extern "C" int rtgpu_render_device(rtgpu_ctx *ctx, const rtgpu_camera *cam, cons
     stats->paths = c[1]; stats->rays = c[2]; stats->nodes = c[3];
     stats->tri_tests = c[4]; stats->sphere_tests = c[5]; stats->scatters = c[6];
   }
+  return 0;
+}
+
+extern "C" int rtgpu_profile_counters(rtgpu_ctx *ctx, uint64_t out[16]) {
+  if (!ctx || !out) return 1;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  HIP_TRY(ctx, hipMemcpy(out, ctx->d_counters, 128, hipMemcpyDeviceToHost));
   return 0;
 }
 

@@ -1,0 +1,61 @@
+// rt.cpp — see rt.hpp.  One global context, like gD3d (code/gfx/gfx.cpp:4-11).
+#include "rt.hpp"
+
+namespace rt {
+static_assert(sizeof(Material) == sizeof(::rtgpu_material), "Material layout");
+static_assert(sizeof(Sphere) == sizeof(::rtgpu_sphere), "Sphere layout");
+static_assert(sizeof(Triangle) == sizeof(::rtgpu_triangle), "Triangle layout");
+static_assert(sizeof(Vec4) == 16 && sizeof(Vec3) == 12, "vector layout");
+
+static ::rtgpu_ctx *gRt_Ctx = nullptr;
+
+void rt_init_or_panic(int device_index) {
+  if (gRt_Ctx) return;
+  if (::rtgpu_create(&gRt_Ctx, device_index) != 0)
+    errf("rt: cannot create the GPU context: %s", ::rtgpu_last_error(nullptr));
+}
+
+void rt_shutdown() {
+  ::rtgpu_destroy(gRt_Ctx);
+  gRt_Ctx = nullptr;
+}
+
+void rt_scene_upload_or_panic(Scene const &scene) {
+  ::rtgpu_scene_desc d = {};
+  d.spheres   = (::rtgpu_sphere const *)scene.spheres;      d.n_spheres   = (uint64_t)scene.spheres_count;
+  d.triangles = (::rtgpu_triangle const *)scene.triangles;  d.n_triangles = (uint64_t)scene.triangles_count;
+  d.materials = (::rtgpu_material const *)scene.materials;  d.n_materials = (uint64_t)scene.materials_count;
+  if (::rtgpu_upload_scene(gRt_Ctx, &d) != 0)
+    errf("rt: scene upload failed: %s", ::rtgpu_last_error(gRt_Ctx));
+}
+
+Camera rt_camera_look_at(Vec3 from, Vec3 at, Vec3 up, f32 vfov_deg, f32 aspect, f32 aperture,
+                         f32 focus_dist) {
+  Camera cam;
+  ::rtgpu_camera_look_at(&cam, from.v, at.v, up.v, vfov_deg, aspect, aperture, focus_dist);
+  return cam;
+}
+
+Render_Settings rt_default_settings(u32 width, u32 height, u32 spp, u32 max_depth) {
+  Render_Settings s;
+  ::rtgpu_default_settings(&s, width, height, spp, max_depth);
+  return s;
+}
+
+void rt_render_or_panic(Camera const &cam, Render_Settings const &settings, Vec4 *accum_out,
+                        u32 *prim_id_out, Render_Stats *stats_out) {
+  if (::rtgpu_render(gRt_Ctx, &cam, &settings, (float *)accum_out, prim_id_out, stats_out) != 0)
+    errf("rt: render failed: %s", ::rtgpu_last_error(gRt_Ctx));
+}
+
+void rt_resolve_rgba8_or_panic(Vec4 const *accum, u32 *rgba8_out, s64 pixel_count) {
+  if (::rtgpu_resolve_rgba8(gRt_Ctx, (float const *)accum, rgba8_out, (uint64_t)pixel_count) != 0)
+    errf("rt: resolve failed: %s", ::rtgpu_last_error(gRt_Ctx));
+}
+
+f32 rt_last_kernel_ms() {
+  f32 ms = 0.f;
+  if (::rtgpu_last_kernel_ms(gRt_Ctx, &ms) != 0) return -1.f;
+  return ms;
+}
+}  // namespace rt

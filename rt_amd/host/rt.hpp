@@ -1,0 +1,95 @@
+// rt.hpp — C++ facade of the trace loop in the reference's own idiom, meant to
+// be dropped into the reference tree as code/rt/rt.hpp (+ rt.cpp) and
+// unity-included from code/first.cpp:10-23 like every other module.
+//
+// It adds files and ONE call in the frame loop (code/first.cpp:78-88, between
+// win32_message_loop() and gfx_render()); it edits no existing module
+// (SURVEY.md §0 item 3, §8b).  Everything here is a thin, allocation-free
+// wrapper over the C ABI in include/rtgpu.h:
+//   * namespace rt, free functions, snake_case with the module prefix,
+//     `_or_panic` for calls that end in errf() on failure
+//     (window_create_or_panic code/window/window.hpp:3, gfx_init_or_panic
+//     code/gfx/gfx.hpp:21, errf code/first.cpp:27-43);
+//   * PODs built from f32/u32/s64/Vec3/Vec4 (code/first.hpp:16-37,
+//     code/math/vec.hxx:18-48); materials are a tagged POD, not a hierarchy;
+//   * long-lived host buffers are the caller's (alloc_perm style,
+//     code/base/memory.cxx:23-34) — nothing here allocates host memory;
+//   * colours 0xRRGGBBAA (code/gfx/gfx.hpp:4-6), rows bottom-up
+//     (code/math/mat.cxx:104-129).
+//
+// Inside the reference tree the scalar typedefs and Vec3/Vec4 come from
+// first.hpp / math/vec.hxx; define RT_FACADE_STANDALONE (the headless Linux
+// driver does) to get layout-identical restatements instead, because
+// first.hpp refuses every compiler but 64-bit MSVC (code/first.hpp:1-11).
+#pragma once
+
+#include "rtgpu.h"
+
+#ifdef RT_FACADE_STANDALONE
+namespace rt {
+using u8  = unsigned char;       // code/first.hpp:16-27
+using u32 = unsigned int;
+using s64 = signed long long;
+using f32 = float;
+union Vec3 {                     // code/math/vec.hxx:18-28 (xy alias omitted)
+  struct { f32 x, y, z; };
+  f32 v[3] = {};
+};
+union Vec4 {                     // code/math/vec.hxx:30-48
+  struct { f32 x, y, z, w; };
+  struct { f32 r, g, b, a; };
+  f32 v[4] = {};
+};
+}  // namespace rt
+template <typename... TArgs>
+[[noreturn]] void errf(char const *fmt, TArgs... args);  // code/first.hpp:95-97
+#endif
+
+namespace rt {
+enum Material_Type : u32 {
+  MATERIAL_LAMBERTIAN = RTGPU_MAT_LAMBERTIAN,
+  MATERIAL_METAL      = RTGPU_MAT_METAL,      // param = fuzz
+  MATERIAL_DIELECTRIC = RTGPU_MAT_DIELECTRIC  // param = index of refraction
+};
+
+// Layout-identical to rtgpu_material / rtgpu_sphere / rtgpu_triangle, so a
+// Scene is handed to the C layer without a copy.
+struct Material { Vec3 albedo; f32 param; u32 type; u32 _unused[3]; };
+struct Sphere   { Vec3 center; f32 radius; u32 material; };
+struct Triangle { Vec3 v0, v1, v2; u32 material; };
+
+struct Scene {
+  Sphere   *spheres;    s64 spheres_count;
+  Triangle *triangles;  s64 triangles_count;
+  Material *materials;  s64 materials_count;
+};
+
+using Camera          = ::rtgpu_camera;    // fill with rt_camera_look_at
+using Render_Settings = ::rtgpu_settings;  // fill with rt_default_settings
+using Render_Stats    = ::rtgpu_stats;
+
+// Render defaults in the style of code/config.hpp:4-12.
+u32 constexpr static RT_SPP       = 16;
+u32 constexpr static RT_MAX_DEPTH = 8;
+
+void rt_init_or_panic(int device_index = 0);
+void rt_shutdown();
+
+void rt_scene_upload_or_panic(Scene const &scene);
+
+[[nodiscard]] Camera rt_camera_look_at(Vec3 from, Vec3 at, Vec3 up, f32 vfov_deg, f32 aspect,
+                                       f32 aperture = 0.f, f32 focus_dist = 10.f);
+[[nodiscard]] Render_Settings rt_default_settings(u32 width, u32 height, u32 spp = RT_SPP,
+                                                  u32 max_depth = RT_MAX_DEPTH);
+
+// accum_out: width*height Vec4 {sum r, sum g, sum b, samples}, caller-owned
+// (a 1080p frame is 33 MB: alloc_perm, not the 8 MB temp arena,
+// code/config.hpp:11).  prim_id_out and stats_out may be null.
+void rt_render_or_panic(Camera const &cam, Render_Settings const &settings, Vec4 *accum_out,
+                        u32 *prim_id_out = nullptr, Render_Stats *stats_out = nullptr);
+
+// accum -> 0xRRGGBBAA (gamma 2), ready for a B8G8R8A8/R8G8B8A8 upload.
+void rt_resolve_rgba8_or_panic(Vec4 const *accum, u32 *rgba8_out, s64 pixel_count);
+
+[[nodiscard]] f32 rt_last_kernel_ms();
+}  // namespace rt

@@ -152,18 +152,40 @@ def test_edge_cases(ra, oracle, gpu_ctx):
             assert sa == sb, name
 
 
-def test_deep_tree_overflows_lds_stack(ra, oracle, gpu_ctx):
-    """Stack deeper than the 16-entry LDS short stack: the scratch overflow path."""
+def test_deep_tree_and_stack_overflow(ra, oracle, gpu_ctx):
+    """A chain of spheres gives a BVH ~30 deep and traversal stacks of > 20
+    entries.  Default context: the whole stack lives in LDS (32 entries).  A
+    second context with RTGPU_STACK_LDS=4 forces everything above 4 entries
+    through the global overflow buffer; both must match the oracle exactly."""
+    import os
     sph = [(float(3.0 ** i), 0.0, 0.0, float(0.25 * 3.0 ** i), 0) for i in range(-16, 40)]
-    sc = make_scene(ra, spheres=sph, materials=[(0, .5, .5, .5, 0)])
+    deep = make_scene(ra, spheres=sph, materials=[(0, .5, .5, .5, 0)])
     cam = ra.look_at((-1e-9, 0.0, 0.0), (1, 0, 0), vfov=30.0, aspect=1.0)
     st = ra.default_settings(32, 32, spp=2, max_depth=4)
     oracle.lib.rto_debug_max_stack(1)
-    (a, ia, sa), (b, ib, sb) = render_both(ra, oracle, gpu_ctx, sc, cam, st, threads=1)
+    (a, ia, sa), (b, ib, sb) = render_both(ra, oracle, gpu_ctx, deep, cam, st, threads=1)
     assert oracle.lib.rto_debug_max_stack(1) > 20
     assert np.array_equal(ia, ib) and (ia != ra.NO_HIT).any()
     assert_bit_equal(a, b, "deep tree")
     assert sa == sb
+    os.environ["RTGPU_STACK_LDS"] = "4"
+    try:
+        small = ra.Context(0)
+    finally:
+        del os.environ["RTGPU_STACK_LDS"]
+    try:
+        (a2, ia2, sa2), _ = render_both(ra, oracle, small, deep, cam, st, threads=1)
+        assert np.array_equal(ia2, ib)
+        assert_bit_equal(a2, b, "deep tree, overflow stack")
+        assert sa2 == sb
+        scene, cam0 = ra.Scene.builtin(1, param=5, aspect=160 / 90)   # depth ~16 > 4 too
+        st0 = ra.default_settings(160, 90, spp=2, max_depth=8)
+        (a3, ia3, sa3), (b3, ib3, sb3) = render_both(ra, oracle, small, scene, cam0, st0)
+        assert np.array_equal(ia3, ib3)
+        assert_bit_equal(a3, b3, "S1, overflow stack")
+        assert sa3 == sb3
+    finally:
+        small.close()
 
 
 def test_thin_lens_and_settings(ra, oracle, gpu_ctx):

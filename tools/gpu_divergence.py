@@ -1,0 +1,22 @@
+"""SIMD lane utilisation per kernel section (profile variant, RTGPU_FLAG_PROFILE)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import rt_amd as ra
+from gpu_perf import CONFIGS
+ctx = ra.Context(0)
+for name in sys.argv[1:] or ["c2", "c3", "c5"]:
+    kind, level, w, h, spp, depth = CONFIGS[name]
+    scene, cam = ra.Scene.builtin(kind, param=level, aspect=w / h)
+    ctx.upload(scene)
+    acc = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+    st = ra.default_settings(w, h, spp=spp, max_depth=depth, flags=ra.FLAG_PROFILE)
+    ctx.render_device(cam, st, acc.data_ptr(), None, None)
+    c = ctx.profile_counters()
+    _, paths, rays, nodes, tris, sphs, scat, w_outer, w_shade, l_shade, w_gen, w_node, w_sph, w_tri, w_trav, l_trav = c
+    u = lambda l, wv: l / (64.0 * wv) if wv else float("nan")
+    print(f"{name}: rays={rays} | wave-level counts per 64 rays: outer={w_outer*64/rays:.2f} shade={w_shade*64/rays:.2f} "
+          f"gen={w_gen*64/rays:.2f} node={w_node*64/rays:.1f} sph={w_sph*64/rays:.2f} tri={w_tri*64/rays:.2f} trav_rounds={w_trav*64/rays:.2f}\n"
+          f"   lane utilisation: shade={u(l_shade, w_shade):.3f} gen={u(paths, w_gen):.3f} node={u(nodes, w_node):.3f} "
+          f"sph={u(sphs, w_sph):.3f} tri={u(tris, w_tri):.3f} trav_round={u(l_trav, w_trav):.3f}", flush=True)
+ctx.close()

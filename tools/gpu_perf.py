@@ -1,0 +1,54 @@
+"""Kernel-time survey over the BASELINE.json configs on one GPU (not the bench
+contract: a developer tool for A/B-ing kernel changes).
+usage: python tools/gpu_perf.py [c2] [c3] [c5] [--reps N]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import rt_amd as ra
+
+CONFIGS = {
+    # name: (kind, level, w, h, spp, depth)
+    "c1": (0, 0, 1280, 720, 1, 8),
+    "c2": (0, 0, 1920, 1080, 16, 8),
+    "c3": (1, 8, 1920, 1080, 8, 8),     # C3 is 64 spp; 8 spp here (same per-ray work)
+    "c5": (2, 7, 1920, 1080, 4, 8),     # S2 at level 7 = 2.6M tris (level 8 = 10.5M)
+    "c5full": (2, 8, 1920, 1080, 4, 8),
+}
+
+def main():
+    names = [a for a in sys.argv[1:] if not a.startswith("--")] or ["c2", "c3", "c5"]
+    reps = 5
+    if "--reps" in sys.argv:
+        reps = int(sys.argv[sys.argv.index("--reps") + 1])
+    ctx = ra.Context(0)
+    for name in names:
+        kind, level, w, h, spp, depth = CONFIGS[name]
+        t0 = time.time()
+        scene, cam = ra.Scene.builtin(kind, param=level, aspect=w / h)
+        t1 = time.time()
+        ctx.upload(scene)
+        t2 = time.time()
+        fs = ctx.flat_scene()
+        acc = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+        st = ra.default_settings(w, h, spp=spp, max_depth=depth, flags=ra.FLAG_STATS)
+        stats = ra.Stats()
+        ctx.render_device(cam, st, acc.data_ptr(), None, None, stats)
+        s = stats.as_dict()
+        st.flags = 0
+        ms = []
+        for _ in range(reps):
+            ctx.render_device(cam, st, acc.data_ptr(), None, None)
+            ms.append(ctx.kernel_ms())
+        ms = np.array(ms)
+        abytes = 64 * s["nodes"] + 48 * s["tri_tests"] + 16 * s["sphere_tests"] + 32 * s["scatters"] + 16 * w * h
+        print(f"{name}: prims={scene.n_prims} nodes={fs.c.n_nodes} depth={fs.c.max_depth} gen={t1-t0:.1f}s "
+              f"build+upload={t2-t1:.1f}s (bvh {fs.c.build_ms/1e3:.1f}s) | {w}x{h}x{spp} rays={s['rays']} "
+              f"nodes/ray={s['nodes']/s['rays']:.1f} tris/ray={s['tri_tests']/s['rays']:.1f} "
+              f"sph/ray={s['sphere_tests']/s['rays']:.1f} B/ray={abytes/s['rays']:.0f} | "
+              f"kernel ms min={ms.min():.3f} med={np.median(ms):.3f} -> {s['rays']/np.median(ms)/1e3:.0f} Mrays/s, "
+              f"{abytes/np.median(ms)/1e6:.0f} GB/s algorithmic", flush=True)
+    ctx.close()
+
+if __name__ == "__main__":
+    main()
