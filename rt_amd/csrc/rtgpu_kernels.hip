@@ -124,32 +124,62 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 // Traversal stack: up to kStackLds entries per lane in LDS, laid out
 // [entry][thread] (lane-consecutive dwords: conflict-free ds_read/ds_write_b32);
 // deeper entries go to a per-lane slice of a global overflow buffer laid out the
-// same way.  Entry 0 holds the sentinel kDone, so pop() needs no emptiness test:
+// same way.  Entry 0 holds the sentinel kDone, so a pop needs no emptiness test:
 // popping the sentinel ends the traversal.  A stack never grows past the tree
-// depth + 1, which the host knows: when that fits in LDS the kernel takes the
-// `lds_only` path (a wave-uniform branch) and every push/pop is a bare
-// ds_write/ds_read.
+// depth + 1, which the host knows: when that fits in LDS it launches the
+// LDS_ONLY instantiation, whose node step has no branch at all - the far child
+// is always written above the top (kept only if both children were hit) and the
+// top is always read (used only if neither was).
+template <bool LDS_ONLY>
 struct Stack {
   uint32_t *lds;        // &lds_stack[tid]
   uint32_t *ovf;        // &ovf[global thread]
   uint32_t ovf_stride;  // threads in the grid
   int lds_entries;      // entries of the LDS part in use (<= kStackLds)
-  bool lds_only;        // tree depth + 1 < lds_entries: the overflow part is unreachable
   int sp;               // next free entry; >= 1 while a traversal is running
   __device__ __forceinline__ void reset() { sp = 1; }
-  __device__ __forceinline__ void push(uint32_t v) {
-    if (lds_only || sp < lds_entries) lds[sp * kBlock] = v;
-    else ovf[(size_t)(sp - lds_entries) * ovf_stride] = v;
-    sp++;
+  __device__ __forceinline__ void store(int at, uint32_t v) {
+    if (LDS_ONLY || at < lds_entries) lds[at * kBlock] = v;
+    else ovf[(size_t)(at - lds_entries) * ovf_stride] = v;
   }
-  __device__ __forceinline__ uint32_t pop() {
-    sp--;
-    uint32_t v;
-    if (lds_only || sp < lds_entries) v = lds[sp * kBlock];
-    else v = ovf[(size_t)(sp - lds_entries) * ovf_stride];
+  __device__ __forceinline__ uint32_t load(int at) {
+    if (LDS_ONLY || at < lds_entries) return lds[at * kBlock];
+    return ovf[(size_t)(at - lds_entries) * ovf_stride];
+  }
+  // node step: push `far_c` if both children were hit, pop if none was
+  __device__ __forceinline__ uint32_t step(bool both, bool none, uint32_t near_c, uint32_t far_c) {
+    if (LDS_ONLY) {
+      uint32_t top = lds[(sp - 1) * kBlock];
+      lds[sp * kBlock] = far_c;
+      sp += (both ? 1 : 0) - (none ? 1 : 0);
+      return none ? top : near_c;
+    }
+    if (both) { store(sp, far_c); sp++; }
+    if (none) { sp--; near_c = load(sp); }
+    return near_c;
+  }
+  // leaf step: pop if the leaf is exhausted
+  __device__ __forceinline__ uint32_t pop_if(bool doit) {
+    if (LDS_ONLY) {
+      uint32_t top = lds[(sp - 1) * kBlock];
+      sp -= doit ? 1 : 0;
+      return top;
+    }
+    uint32_t v = kDone;
+    if (doit) { sp--; v = load(sp); }
     return v;
   }
 };
+
+// Lanes of the wave for which p holds, as a 32-bit scalar (s_bcnt1_i32_b64).
+// Written as asm because the generic popcount is i64 and hipcc then carries the
+// vote's comparisons as 64-bit VALU compares of scalars.
+__device__ __forceinline__ int wave_count(bool p) {
+  unsigned long long m = __ballot(p);
+  int r;
+  asm("s_bcnt1_i32_b64 %0, %1" : "=s"(r) : "s"(m) : "scc");
+  return r;
+}
 
 // REFILL: leave the traversal loop as soon as fewer than REFILL lanes of the
 // wave are still traversing (and at least one has finished), so that finished
@@ -164,7 +194,7 @@ __device__ __forceinline__ void wave_tick(unsigned lane, unsigned long long &c) 
   if (lane == (unsigned)__ffsll((long long)m) - 1u) c++;
 }
 
-template <int STATS, int REFILL>
+template <int STATS, int REFILL, bool LDS_ONLY>
 __global__ __launch_bounds__(kBlock) void trace_kernel(const KParams P) {
   __shared__ uint32_t lds_stack[kStackLds * kBlock];
   const unsigned tid = threadIdx.x;
@@ -189,13 +219,12 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const KParams P) {
   uint32_t hit_slot = 0, cur = kDone;
   int hit_kind = 0;  // 0 none, 1 sphere, 2 triangle
   unsigned pool_next = 0, pool_end = 0;  // wave-local slice of the work queue (wave-uniform)
-  Stack stk;
+  Stack<LDS_ONLY> stk;
   stk.lds = lds_stack + tid;
   stk.ovf_stride = gridDim.x * kBlock;
   stk.ovf = P.ovf_stack + (size_t)blockIdx.x * kBlock + tid;
   stk.sp = 1;
   stk.lds_entries = (int)P.stack_lds;
-  stk.lds_only = P.stack_lds_only != 0u;
   lds_stack[tid] = kDone;  // sentinel under every lane's stack (never overwritten)
   const float tmin = P.tmin;
   const char *const nodes_base = (const char *)P.nodes;
@@ -412,61 +441,63 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const KParams P) {
 
     // ---- (4) closest hit: ordered stack traversal (rows a3-a5) ------------------
     // Every lane walks its own ray in the oracle's order; what the WAVE executes
-    // next is put to a vote: the step kind (inner node / sphere leaf / triangle
-    // leaf) that most lanes are waiting for runs, the other lanes sit the round
-    // out.  A plain while-while loop ran the node step for as few as one lane
-    // (measured 13-27 % lane utilisation); the vote keeps each step above half
-    // of the lanes that are still traversing.
-    const int n_entry = __popcll(__ballot(cur != kDone));
+    // next is put to a vote between the lanes waiting at an inner node and the
+    // lanes waiting at a leaf: the majority's step kind runs, and keeps running
+    // while it stays the majority (one popcount per step), the other lanes sit
+    // those steps out.  A plain while-while loop ran the node step for as few as
+    // one lane (measured 13-27 % lane utilisation in the node step).
+    // A leaf step tests ONE primitive and advances the reference in place
+    // (first+1, count-1), so lanes with short leaves never wait for long ones.
+    // The intersection tests are branch-free: a rejected candidate produces
+    // values (possibly inf/NaN) that fail the final comparisons, exactly where
+    // the oracle returns early.
+    const int n_entry = wave_count(cur != kDone);
     for (;;) {
-      // reference encoding read as a signed int: inner node >= 0; triangle leaf
-      // < -2^30; sphere leaf in [-2^30, -2]; kDone == -1
-      const int icur = (int)cur;
-      const bool trav = icur != -1;
-      const bool at_node = icur >= 0;
-      const bool at_tri = icur < (int)0xC0000000u;
-      const bool at_sph = trav && !at_node && !at_tri;
-      const int n_trav = __builtin_popcountll(__ballot(trav));
-      const int n_node = __builtin_popcountll(__ballot(at_node));
-      const int n_tri = __builtin_popcountll(__ballot(at_tri));
-      const int n_sph = n_trav - n_node - n_tri;
+      // reference read as a signed int: inner node >= 0; leaf < -1; kDone == -1
+      const int n_trav = wave_count((int)cur != -1);
       if (n_trav == 0 || (n_trav < REFILL && n_trav < n_entry)) break;  // wave-uniform
-      if (STATS == 2) { wave_tick(lane, w_trav); if (trav) l_trav++; }
-      if (n_node >= n_sph && n_node >= n_tri) {
-        if (at_node) {
-          if (STATS == 2) wave_tick(lane, w_node);
-          const float4 *n = (const float4 *)(nodes_base + (cur << 6));  // 32-bit offset: < 4 GiB of nodes
-          float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
-          if (STATS) n_nodes++;
-          // child 0: lo (q0.x q0.y q0.z) hi (q0.w q1.x q1.y); child 1: lo (q1.z q1.w q2.x) hi (q2.y q2.z q2.w)
-          float a0x = __builtin_fmaf(q0.x, inv.x, noi.x), a1x = __builtin_fmaf(q0.w, inv.x, noi.x);
-          float a0y = __builtin_fmaf(q0.y, inv.y, noi.y), a1y = __builtin_fmaf(q1.x, inv.y, noi.y);
-          float a0z = __builtin_fmaf(q0.z, inv.z, noi.z), a1z = __builtin_fmaf(q1.y, inv.z, noi.z);
-          float tn0 = fmax_(fmax_(fmin_(a0x, a1x), fmin_(a0y, a1y)), fmax_(fmin_(a0z, a1z), tmin));
-          float tf0 = fmin_(fmin_(fmax_(a0x, a1x), fmax_(a0y, a1y)), fmin_(fmax_(a0z, a1z), tbest));
-          float b0x = __builtin_fmaf(q1.z, inv.x, noi.x), b1x = __builtin_fmaf(q2.y, inv.x, noi.x);
-          float b0y = __builtin_fmaf(q1.w, inv.y, noi.y), b1y = __builtin_fmaf(q2.z, inv.y, noi.y);
-          float b0z = __builtin_fmaf(q2.x, inv.z, noi.z), b1z = __builtin_fmaf(q2.w, inv.z, noi.z);
-          float tn1 = fmax_(fmax_(fmin_(b0x, b1x), fmin_(b0y, b1y)), fmax_(fmin_(b0z, b1z), tmin));
-          float tf1 = fmin_(fmin_(fmax_(b0x, b1x), fmax_(b0y, b1y)), fmin_(fmax_(b0z, b1z), tbest));
-          uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
-          // an empty child (scenes of < 2 primitives) has its box at +inf and can
-          // never pass: tfar <= tbest <= FLT_MAX < tnear
-          bool h0 = tn0 <= tf0;
-          bool h1 = tn1 <= tf1;
-          // both hit: nearer first (tie: child 0), the other is pushed
-          bool swap = tn1 < tn0;
-          uint32_t near_c = (h0 && !(h1 && swap)) ? c0 : c1;
-          uint32_t far_c = swap ? c0 : c1;
-          if (h0 && h1) stk.push(far_c);
-          if (!(h0 || h1)) near_c = stk.pop();
-          cur = near_c;
-        }
-      } else if (n_sph >= n_tri) {
-        if (at_sph) {
-          uint32_t first = RTGPU_REF_FIRST(cur), count = RTGPU_REF_COUNT(cur);
-#pragma unroll 1
-          for (uint32_t i = first; i < first + count; i++) {
+      int n_node = wave_count((int)cur >= 0);
+      if (STATS == 2) { wave_tick(lane, w_trav); if ((int)cur != -1) l_trav++; }
+      if (2 * n_node >= n_trav) {
+        do {
+          if ((int)cur >= 0) {
+            if (STATS == 2) wave_tick(lane, w_node);
+            const float4 *n = (const float4 *)(nodes_base + (cur << 6));  // 32-bit offset: < 4 GiB of nodes
+            float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
+            if (STATS) n_nodes++;
+            // child 0: lo (q0.x q0.y q0.z) hi (q0.w q1.x q1.y); child 1: lo (q1.z q1.w q2.x) hi (q2.y q2.z q2.w)
+            float a0x = __builtin_fmaf(q0.x, inv.x, noi.x), a1x = __builtin_fmaf(q0.w, inv.x, noi.x);
+            float a0y = __builtin_fmaf(q0.y, inv.y, noi.y), a1y = __builtin_fmaf(q1.x, inv.y, noi.y);
+            float a0z = __builtin_fmaf(q0.z, inv.z, noi.z), a1z = __builtin_fmaf(q1.y, inv.z, noi.z);
+            float tn0 = fmax_(fmax_(fmin_(a0x, a1x), fmin_(a0y, a1y)), fmax_(fmin_(a0z, a1z), tmin));
+            float tf0 = fmin_(fmin_(fmax_(a0x, a1x), fmax_(a0y, a1y)), fmin_(fmax_(a0z, a1z), tbest));
+            float b0x = __builtin_fmaf(q1.z, inv.x, noi.x), b1x = __builtin_fmaf(q2.y, inv.x, noi.x);
+            float b0y = __builtin_fmaf(q1.w, inv.y, noi.y), b1y = __builtin_fmaf(q2.z, inv.y, noi.y);
+            float b0z = __builtin_fmaf(q2.x, inv.z, noi.z), b1z = __builtin_fmaf(q2.w, inv.z, noi.z);
+            float tn1 = fmax_(fmax_(fmin_(b0x, b1x), fmin_(b0y, b1y)), fmax_(fmin_(b0z, b1z), tmin));
+            float tf1 = fmin_(fmin_(fmax_(b0x, b1x), fmax_(b0y, b1y)), fmin_(fmax_(b0z, b1z), tbest));
+            uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
+            // an empty child (scenes of < 2 primitives) has its box at +inf and can
+            // never pass: tfar <= tbest <= FLT_MAX < tnear
+            bool h0 = tn0 <= tf0;
+            bool h1 = tn1 <= tf1;
+            // both hit: nearer first (tie: child 0), the other is pushed
+            bool swap = tn1 < tn0;
+            uint32_t near_c = (h0 && !(h1 && swap)) ? c0 : c1;
+            uint32_t far_c = swap ? c0 : c1;
+            cur = stk.step(h0 && h1, !(h0 || h1), near_c, far_c);
+          }
+          n_node = wave_count((int)cur >= 0);
+        } while (n_node > 0 && 2 * n_node >= n_trav);
+      } else {
+        int n_leaf;
+        do {
+          const bool at_leaf = (int)cur < -1;
+          const bool at_sph = at_leaf && (cur & RTGPU_REF_SPHERE);
+          const bool at_tri = at_leaf && !(cur & RTGPU_REF_SPHERE);
+          const uint32_t i = RTGPU_REF_FIRST(cur);
+          const bool last = (cur & (7u << 27)) == 0u;  // count-1 == 0
+          if (at_sph) {
             float4 s = *(const float4 *)(sphs_base + (i << 4));
             if (STATS) n_sphs++;
             if (STATS == 2) wave_tick(lane, w_sph);
@@ -474,21 +505,15 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const KParams P) {
             float hb = dot(oc, rd);
             float cc = dot(oc, oc) - s.w * s.w;
             float disc = hb * hb - cc;
-            if (!(disc < 0.0f)) {
-              float sq = __builtin_sqrtf(disc);
-              float t = -hb - sq;
-              bool ok = t > tmin && t < tbest;
-              if (!ok) { t = -hb + sq; ok = t > tmin && t < tbest; }
-              if (ok) { tbest = t; hit_slot = i; hit_kind = 1; }
-            }
+            float sq = __builtin_sqrtf(disc);  // NaN for a negative discriminant: fails every test below
+            float t = -hb - sq;
+            bool ok = t > tmin && t < tbest;
+            float t2 = -hb + sq;
+            bool ok2 = t2 > tmin && t2 < tbest;
+            t = ok ? t : t2;
+            if (ok || ok2) { tbest = t; hit_slot = i; hit_kind = 1; }
           }
-          cur = stk.pop();
-        }
-      } else {
-        if (at_tri) {
-          uint32_t first = RTGPU_REF_FIRST(cur), count = RTGPU_REF_COUNT(cur);
-#pragma unroll 1
-          for (uint32_t i = first; i < first + count; i++) {
+          if (at_tri) {
             const float4 *tp = (const float4 *)(tris_base + i * 48u);  // 32-bit offset: < 4 GiB of triangles
             float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
             if (STATS) n_tris++;
@@ -496,22 +521,24 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const KParams P) {
             V3 v0 = mk(t0.x, t0.y, t0.z), e1 = mk(t1.x, t1.y, t1.z), e2 = mk(t2.x, t2.y, t2.z);
             V3 pvec = cross(rd, e2);
             float det = dot(e1, pvec);
-            if (!(__builtin_fabsf(det) < 1e-30f)) {
-              float inv_det = 1.0f / det;
-              V3 tvec = ro - v0;
-              float u = dot(tvec, pvec) * inv_det;
-              if (!(u < 0.0f || u > 1.0f)) {
-                V3 qvec = cross(tvec, e1);
-                float v = dot(rd, qvec) * inv_det;
-                if (!(v < 0.0f || u + v > 1.0f)) {
-                  float t = dot(e2, qvec) * inv_det;
-                  if (t > tmin && t < tbest) { tbest = t; hit_slot = i; hit_kind = 2; }
-                }
-              }
-            }
+            bool valid = !(__builtin_fabsf(det) < 1e-30f);
+            float inv_det = 1.0f / det;
+            V3 tvec = ro - v0;
+            float u = dot(tvec, pvec) * inv_det;
+            valid = valid && !(u < 0.0f || u > 1.0f);
+            V3 qvec = cross(tvec, e1);
+            float v = dot(rd, qvec) * inv_det;
+            valid = valid && !(v < 0.0f || u + v > 1.0f);
+            float t = dot(e2, qvec) * inv_det;
+            if (valid && t > tmin && t < tbest) { tbest = t; hit_slot = i; hit_kind = 2; }
           }
-          cur = stk.pop();
-        }
+          if (at_leaf) {
+            uint32_t next = cur + 1u - (1u << 27);  // first+1, count-1
+            uint32_t popped = stk.pop_if(last);
+            cur = last ? popped : next;
+          }
+          n_leaf = wave_count((int)cur < -1);
+        } while (n_leaf > 0 && 2 * n_leaf > n_trav);
       }
     }
   }
@@ -618,13 +645,12 @@ namespace {
 // code path; the threshold only changes WHEN finished lanes are refilled, never
 // what a path computes.  RTGPU_REFILL (0/16/32/48) selects it for experiments.
 using KernelFn = void (*)(const KParams);
-struct Variant { int refill; KernelFn plain, stats, profile; };
-const Variant kVariants[] = {
-    {0, trace_kernel<0, 0>, trace_kernel<1, 0>, trace_kernel<2, 0>},
-    {16, trace_kernel<0, 16>, trace_kernel<1, 16>, trace_kernel<2, 16>},
-    {32, trace_kernel<0, 32>, trace_kernel<1, 32>, trace_kernel<2, 32>},
-    {48, trace_kernel<0, 48>, trace_kernel<1, 48>, trace_kernel<2, 48>},
-};
+struct Variant { int refill; KernelFn fn[3][2]; };  // [plain, stats, profile][overflow-capable, LDS-only]
+#define RTGPU_VARIANT(R)                                                                   \
+  {R, {{trace_kernel<0, R, false>, trace_kernel<0, R, true>},                               \
+       {trace_kernel<1, R, false>, trace_kernel<1, R, true>},                               \
+       {trace_kernel<2, R, false>, trace_kernel<2, R, true>}}}
+const Variant kVariants[] = {RTGPU_VARIANT(0), RTGPU_VARIANT(16), RTGPU_VARIANT(32)};
 constexpr int kDefaultVariant = 1;  // refill below 16 traversing lanes (measured best on C2/C3/C5)
 
 bool hip_fail(rtgpu_ctx *ctx, hipError_t e, const char *what) {
@@ -717,8 +743,8 @@ extern "C" int rtgpu_create(rtgpu_ctx **out, int device_index) {
     if (want >= 2 && want <= kStackLds) ctx->stack_lds = want;
   }
   int b0 = 0, b1 = 0;
-  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b0, kVariants[ctx->variant].plain, kBlock, 0);
-  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b1, kVariants[ctx->variant].stats, kBlock, 0);
+  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b0, kVariants[ctx->variant].fn[0][0], kBlock, 0);
+  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b1, kVariants[ctx->variant].fn[2][0], kBlock, 0);
   if (const char *env = std::getenv("RTGPU_BLOCKS_PER_CU")) {
     int want = std::atoi(env);
     if (want > 0 && want < b0) b0 = want;
@@ -832,7 +858,7 @@ extern "C" int rtgpu_render_device(rtgpu_ctx *ctx, const rtgpu_camera *cam, cons
     if ((size_t)grid * kBlock > ctx->ovf_threads) { ctx->err = "internal: grid exceeds the overflow stack"; return 2; }
     const Variant &var = kVariants[ctx->variant];
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
-    KernelFn fn = (s->flags & RTGPU_FLAG_PROFILE) ? var.profile : want_stats ? var.stats : var.plain;
+    KernelFn fn = var.fn[(s->flags & RTGPU_FLAG_PROFILE) ? 2 : want_stats ? 1 : 0][P.stack_lds_only ? 1 : 0];
     hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), 0, stream, P);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev1, stream));
