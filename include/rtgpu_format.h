@@ -51,6 +51,11 @@ typedef struct rtgpu_sph {
   float c[3]; float r;
 } rtgpu_sph;
 
+/* Node order: node 0 is the root; the first RTGPU_TOP_NODES nodes are numbered
+ * breadth-first (index < K  <=>  among the K nodes nearest the root: the kernel
+ * keeps as many of them in LDS as fit), the remaining nodes depth-first. */
+#define RTGPU_TOP_NODES 4096u
+
 /* Traversal stack bound: the builder never produces a tree deeper than this
  * (root = depth 0), and both the kernel and the oracle size stacks from it. */
 #define RTGPU_MAX_TREE_DEPTH 62u

@@ -328,6 +328,39 @@ int flatten_scene(const rtgpu_scene_desc *scene, rtgpu_flat_scene *out, std::str
     uint32_t r = B.build(0, n, 0, bounds);
     if (r != 0) { err = "internal: root is not node 0"; return 1; }
   }
+  // Node order: the builder emits depth-first (a subtree is contiguous, which
+  // keeps deep traversal steps within few cache lines); the first
+  // RTGPU_TOP_NODES nodes are then re-numbered breadth-first, so that "index <
+  // K" means "one of the K nodes nearest the root" - the part of the tree every
+  // ray walks, which the kernel keeps in LDS.  Pure renumbering: boxes, child
+  // order and therefore every traversal are unchanged.
+  if (B.nodes.size() > 2) {
+    const size_t nn = B.nodes.size();
+    std::vector<uint32_t> new_of_old(nn, 0xFFFFFFFFu), order;
+    order.reserve(nn);
+    order.push_back(0);
+    new_of_old[0] = 0;
+    for (size_t head = 0; head < order.size() && order.size() < RTGPU_TOP_NODES; head++) {
+      const rtgpu_node &nd = B.nodes[order[head]];
+      const uint32_t ch[2] = {nd.child0, nd.child1};
+      for (uint32_t c : ch)
+        if (!(c & RTGPU_REF_LEAF) && order.size() < RTGPU_TOP_NODES) {
+          new_of_old[c] = (uint32_t)order.size();
+          order.push_back(c);
+        }
+    }
+    for (size_t i = 0; i < nn; i++)  // the rest keeps its depth-first order
+      if (new_of_old[i] == 0xFFFFFFFFu) { new_of_old[i] = (uint32_t)order.size(); order.push_back((uint32_t)i); }
+    std::vector<rtgpu_node> re(nn);
+    for (size_t k = 0; k < nn; k++) {
+      rtgpu_node nd = B.nodes[order[k]];
+      if (!(nd.child0 & RTGPU_REF_LEAF)) nd.child0 = new_of_old[nd.child0];
+      if (!(nd.child1 & RTGPU_REF_LEAF)) nd.child1 = new_of_old[nd.child1];
+      re[k] = nd;
+    }
+    B.nodes.swap(re);
+  }
+
   if (B.nodes.size() * sizeof(rtgpu_node) >= (1ull << 32) || B.tris.size() * sizeof(rtgpu_tri) >= (1ull << 32)) {
     err = "scene too large: node or triangle buffer would reach 4 GiB (the kernel uses 32-bit offsets)";
     return 1;

@@ -31,8 +31,9 @@
 
 namespace {
 
-constexpr int      kBlock      = 256;
-constexpr int      kStackLds   = 32;   // entries per lane in LDS (32 KiB per 256-thread block)
+constexpr int      kBlock      = 1024; // one block per CU: 16 waves share one LDS copy of the top of the BVH
+constexpr int      kStackLds   = 32;   // most entries per lane the LDS stack may get (4 KiB per entry per block)
+constexpr int      kLdsBytes   = 160 * 1024;  // LDS per CU on gfx950; one block takes all of it
 constexpr int      kStackOvf   = RTGPU_MAX_TREE_DEPTH + 2;  // global overflow entries per lane (covers stack_lds >= 2)
 constexpr uint32_t kDone       = 0xFFFFFFFFu;  // == RTGPU_REF_EMPTY, has the leaf bit
 constexpr unsigned kChunk      = 64;   // work items drawn per queue atomic (one 8x8 pixel block)
@@ -55,6 +56,7 @@ struct KParams {
   uint32_t width, height, spp, sample_offset, max_depth, seed;
   uint32_t ts_log2, tiles_x, rank, world, n_items, flags;
   uint32_t stack_lds, stack_lds_only;
+  uint32_t n_cached;  // nodes [0, n_cached) are read from the LDS copy
 };
 
 struct V3 { float x, y, z; };
@@ -196,7 +198,15 @@ __device__ __forceinline__ void wave_tick(unsigned lane, unsigned long long &c) 
 
 template <int STATS, int REFILL, bool LDS_ONLY>
 __global__ __launch_bounds__(kBlock) void trace_kernel(const KParams P) {
-  __shared__ uint32_t lds_stack[kStackLds * kBlock];
+  // LDS: [traversal stacks: stack_lds x kBlock u32][node cache: 4 planes x n_cached float4]
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  uint32_t *const lds_stack = smem;
+  // explicit LDS address space: otherwise hipcc folds the "cached or not" choice
+  // of the node fetch into ONE flat load of a selected generic pointer, and the
+  // LDS reads go through the texture addresser like global ones
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) f4 lds_f4;
+  lds_f4 *const node_cache = (lds_f4 *)(smem + P.stack_lds * kBlock);
   const unsigned tid = threadIdx.x;
   const unsigned lane = lane_id();
 
@@ -226,6 +236,19 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const KParams P) {
   stk.sp = 1;
   stk.lds_entries = (int)P.stack_lds;
   lds_stack[tid] = kDone;  // sentinel under every lane's stack (never overwritten)
+  // LDS copy of the n_cached nodes nearest the root (the builder numbers them
+  // breadth-first), as four planes [16-byte quarter][node]: lanes of a wave read
+  // quarter j of DIFFERENT nodes, and in this layout consecutive nodes sit in
+  // consecutive 16-byte bank groups (measured 56 cycles per 64-lane node fetch
+  // vs 142 for node-major LDS and 181 through the vector L1, tools/ubench).
+  const uint32_t n_cached = P.n_cached;
+  for (uint32_t i = tid; i < n_cached * 4u; i += kBlock)
+  {
+      float4 v = P.nodes[i];
+      f4 w = {v.x, v.y, v.z, v.w};
+      node_cache[(i & 3u) * n_cached + (i >> 2)] = w;
+    }
+  __syncthreads();
   const float tmin = P.tmin;
   const char *const nodes_base = (const char *)P.nodes;
   const char *const tris_base = (const char *)P.tris;
@@ -462,8 +485,18 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const KParams P) {
         do {
           if ((int)cur >= 0) {
             if (STATS == 2) wave_tick(lane, w_node);
-            const float4 *n = (const float4 *)(nodes_base + (cur << 6));  // 32-bit offset: < 4 GiB of nodes
-            float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
+            float4 q0, q1, q2, q3;
+            if (cur < n_cached) {
+              f4 w0 = node_cache[cur], w1 = node_cache[n_cached + cur], w2 = node_cache[2u * n_cached + cur],
+                 w3 = node_cache[3u * n_cached + cur];
+              q0 = make_float4(w0.x, w0.y, w0.z, w0.w);
+              q1 = make_float4(w1.x, w1.y, w1.z, w1.w);
+              q2 = make_float4(w2.x, w2.y, w2.z, w2.w);
+              q3 = make_float4(w3.x, w3.y, w3.z, w3.w);
+            } else {
+              const float4 *n = (const float4 *)(nodes_base + (cur << 6));  // 32-bit offset: < 4 GiB of nodes
+              q0 = n[0]; q1 = n[1]; q2 = n[2]; q3 = n[3];
+            }
             if (STATS) n_nodes++;
             // child 0: lo (q0.x q0.y q0.z) hi (q0.w q1.x q1.y); child 1: lo (q1.z q1.w q2.x) hi (q2.y q2.z q2.w)
             float a0x = __builtin_fmaf(q0.x, inv.x, noi.x), a1x = __builtin_fmaf(q0.w, inv.x, noi.x);
@@ -630,7 +663,8 @@ struct rtgpu_ctx {
   bool timed = false;
   int num_cus = 0;
   int variant = 0;              // index into kVariants (refill threshold), see rtgpu_create
-  int stack_lds = kStackLds;    // LDS stack entries in use (RTGPU_STACK_LDS shrinks it for tests)
+  int stack_lds = kStackLds;    // cap on LDS stack entries (RTGPU_STACK_LDS shrinks it for tests)
+  bool no_node_cache = false;   // RTGPU_NO_NODE_CACHE=1: every node through the vector L1 (experiments)
   int blocks_per_cu[2] = {0, 0};
   uint32_t *d_ovf = nullptr;    // traversal-stack overflow, sized for the largest grid
   size_t ovf_threads = 0;
@@ -738,21 +772,23 @@ extern "C" int rtgpu_create(rtgpu_ctx **out, int device_index) {
     for (int i = 0; i < (int)(sizeof(kVariants) / sizeof(kVariants[0])); i++)
       if (kVariants[i].refill == want) ctx->variant = i;
   }
+  if (const char *env = std::getenv("RTGPU_NO_NODE_CACHE")) ctx->no_node_cache = std::atoi(env) != 0;
   if (const char *env = std::getenv("RTGPU_STACK_LDS")) {
     int want = std::atoi(env);
     if (want >= 2 && want <= kStackLds) ctx->stack_lds = want;
   }
-  int b0 = 0, b1 = 0;
-  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b0, kVariants[ctx->variant].fn[0][0], kBlock, 0);
-  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b1, kVariants[ctx->variant].fn[2][0], kBlock, 0);
-  if (const char *env = std::getenv("RTGPU_BLOCKS_PER_CU")) {
-    int want = std::atoi(env);
-    if (want > 0 && want < b0) b0 = want;
-    if (want > 0 && want < b1) b1 = want;
-  }
-  ctx->blocks_per_cu[0] = b0 > 0 ? b0 : 1;
-  ctx->blocks_per_cu[1] = b1 > 0 ? b1 : 1;
-  ctx->ovf_threads = (size_t)ctx->num_cus * (size_t)(b0 > b1 ? b0 : b1) * kBlock;
+  // one 1024-thread block per CU, holding all 160 KiB of its LDS
+  for (const Variant &v : kVariants)
+    for (int a = 0; a < 3; a++)
+      for (int b = 0; b < 2; b++)
+        if ((e = hipFuncSetAttribute((const void *)v.fn[a][b], hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     kLdsBytes)) != hipSuccess) {
+          rtgpu::set_global_error(std::string("rtgpu_create: LDS attribute: ") + hipGetErrorString(e));
+          rtgpu_destroy(ctx);
+          return 2;
+        }
+  ctx->blocks_per_cu[0] = ctx->blocks_per_cu[1] = 1;
+  ctx->ovf_threads = (size_t)ctx->num_cus * kBlock;
   if (ctx->ovf_threads == 0) ctx->ovf_threads = kBlock;
   if ((e = hipMalloc((void **)&ctx->d_ovf, ctx->ovf_threads * kStackOvf * sizeof(uint32_t))) != hipSuccess) {
     rtgpu::set_global_error(std::string("rtgpu_create: overflow stack: ") + hipGetErrorString(e));
@@ -844,9 +880,20 @@ extern "C" int rtgpu_render_device(rtgpu_ctx *ctx, const rtgpu_camera *cam, cons
   P.max_depth = s->max_depth; P.seed = s->seed;
   P.ts_log2 = ts_log2; P.tiles_x = g.tiles_x; P.rank = s->rank; P.world = s->world_size;
   P.n_items = (uint32_t)n_items; P.flags = s->flags;
-  P.stack_lds = (uint32_t)ctx->stack_lds;
-  // pushes never exceed the tree depth; +1 for the sentinel
-  P.stack_lds_only = (ctx->host.max_depth + 1u < (uint32_t)ctx->stack_lds) ? 1u : 0u;
+  // LDS budget of the one block per CU: the stack gets what the tree depth
+  // needs (pushes never exceed the depth; +1 sentinel, +1 for the unconditional
+  // store above the top), the node cache gets the rest.
+  uint32_t need = ctx->host.max_depth + 2u;
+  uint32_t stack_lds = need < 8u ? 8u : need;
+  if (stack_lds > (uint32_t)ctx->stack_lds) stack_lds = (uint32_t)ctx->stack_lds;  // kStackLds, or RTGPU_STACK_LDS
+  P.stack_lds = stack_lds;
+  P.stack_lds_only = need <= stack_lds ? 1u : 0u;
+  size_t lds_left = (size_t)kLdsBytes - (size_t)stack_lds * kBlock * sizeof(uint32_t);
+  uint64_t fit = lds_left / sizeof(rtgpu_node);
+  uint64_t top = ctx->host.n_nodes < RTGPU_TOP_NODES ? ctx->host.n_nodes : RTGPU_TOP_NODES;
+  P.n_cached = (uint32_t)(fit < top ? fit : top);
+  if (ctx->no_node_cache) P.n_cached = 0;
+  size_t lds_bytes = (size_t)stack_lds * kBlock * sizeof(uint32_t) + (size_t)P.n_cached * sizeof(rtgpu_node);
 
   bool want_stats = (s->flags & (RTGPU_FLAG_STATS | RTGPU_FLAG_PROFILE)) != 0;
   HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 128, stream));
@@ -859,7 +906,7 @@ extern "C" int rtgpu_render_device(rtgpu_ctx *ctx, const rtgpu_camera *cam, cons
     const Variant &var = kVariants[ctx->variant];
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
     KernelFn fn = var.fn[(s->flags & RTGPU_FLAG_PROFILE) ? 2 : want_stats ? 1 : 0][P.stack_lds_only ? 1 : 0];
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), 0, stream, P);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), lds_bytes, stream, P);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev1, stream));
     ctx->timed = true;
