@@ -84,11 +84,20 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
+    # RT_BENCH_SHARE_GPU=1 is a REHEARSAL mode for a one-GPU box: every rank uses
+    # GPU 0 and the gather goes through gloo on host copies.  Never used by the
+    # driver; the JSON says so in config.workload.
+    share_gpu = os.environ.get("RT_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     W, H, depth = args.width, args.height, args.depth
     spp = args.spp * world
@@ -113,7 +122,14 @@ def main():
         ms = None
         if compact:
             # real exchange step of the path: tiles -> rank 0
-            dist.gather(accum, list(gathered.chunk(world)) if rank == 0 else None, dst=0)
+            if share_gpu:  # rehearsal only: gloo cannot move device tensors
+                host = accum.cpu()
+                parts = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
+                dist.gather(host, parts, dst=0)
+                if rank == 0:
+                    gathered.copy_(torch.cat(parts))
+            else:
+                dist.gather(accum, list(gathered.chunk(world)) if rank == 0 else None, dst=0)
             if rank == 0:
                 ctx.untile_device(gathered.data_ptr(), image.data_ptr(), W, H, tile, world, 16,
                                   stream.cuda_stream)
@@ -145,6 +161,8 @@ def main():
 
     t_all = torch.tensor([dt], dtype=torch.float64, device=dev)
     rays_all = torch.tensor([float(counts["rays"])], dtype=torch.float64, device=dev)
+    if share_gpu:
+        t_all, rays_all = t_all.cpu(), rays_all.cpu()
     if world > 1:
         dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
         dist.all_reduce(rays_all, op=dist.ReduceOp.SUM)
@@ -166,7 +184,8 @@ def main():
                 "workload": f"C2: procedural scene S0 (RTIOW cover, {scene.n_prims} prims), "
                             f"{W}x{H}, {args.spp} spp per GPU ({spp} spp total), depth {depth}, "
                             f"pinhole, 64x64 tiles interleaved over {world} GPU(s)"
-                            + (", RCCL gather to rank 0" if compact else ""),
+                            + (", RCCL gather to rank 0" if compact and not share_gpu else "")
+                            + (" [REHEARSAL: all ranks on one GPU, gloo gather via host]" if share_gpu else ""),
                 "rays_per_step": int(rays_per_step), "paths_per_step": W * H * spp,
                 "ms_per_frame_1080p_16spp": round(dt / args.steps * 1e3, 4) if world == 1 else None,
             },

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define RTGPU_ABI_VERSION 1u
+#define RTGPU_ABI_VERSION 2u
 
 /* ---- scene description (host side, caller-owned) ------------------------ */
 
@@ -114,6 +114,11 @@ typedef struct rtgpu_settings {
   uint32_t rank;           /* this context renders tiles t with t % world == rank */
   uint32_t world_size;
   uint32_t flags;
+  uint32_t chunk_samples;  /* samples per work item, >= 1: a pixel's frame sum is
+                            * (((C0 + C1) + C2) ...) where chunk Ck sums its samples
+                            * [k*chunk_samples, min((k+1)*chunk_samples, spp)) in
+                            * order.  Finer chunks = shorter tail of the persistent
+                            * kernel; the value is part of the arithmetic contract */
 } rtgpu_settings;
 
 typedef struct rtgpu_stats {

@@ -488,7 +488,8 @@ static v3 trace_path(const job_t *J, uint32_t x, uint32_t y, uint32_t sample, ui
  * accum (float4 per pixel, image layout, row 0 = bottom) and prim_id (u32 per
  * pixel, primary hit of sample `sample_offset`).  Pixels outside the crop, or
  * in tiles another rank owns, are left untouched.  Per pixel the frame sum is
- * formed sequentially over samples (s = 0..spp-1), then
+ * the in-order sum of chunk sums, each chunk the in-order sum of chunk_samples
+ * consecutive samples (rtgpu_settings.chunk_samples), then
  *   out = (ACCUMULATE ? in : 0) + (sum.r, sum.g, sum.b, (f32)spp).
  */
 RTO_API int rto_render(const rtgpu_flat_scene *fs, const rtgpu_camera *cam, const rtgpu_settings *st,
@@ -501,7 +502,8 @@ RTO_API int rto_render(const rtgpu_flat_scene *fs, const rtgpu_camera *cam, cons
   sc.sph_meta = fs->sphere_meta;
   sc.mats = (const rtgpu_material *)fs->materials;
   sc.n_nodes = fs->n_nodes; sc.n_tris = fs->n_tris; sc.n_sphs = fs->n_spheres; sc.n_mats = fs->n_materials;
-  if (!st->width || !st->height || !st->tile_size || !st->world_size || st->rank >= st->world_size)
+  if (!st->width || !st->height || !st->tile_size || !st->world_size || st->rank >= st->world_size ||
+      !st->chunk_samples)
     return 1;
   if (x1 > st->width) x1 = st->width;
   if (y1 > st->height) y1 = st->height;
@@ -529,13 +531,19 @@ RTO_API int rto_render(const rtgpu_flat_scene *fs, const rtgpu_camera *cam, cons
       for (uint32_t x = x0; x < x1; x++) {
         uint32_t tile = (y / st->tile_size) * tiles_x + x / st->tile_size;
         if (tile % st->world_size != st->rank) continue;
+        /* frame sum = (((C0 + C1) + C2) ...), chunk Ck = its samples summed in order */
         v3 sum = {0.0f, 0.0f, 0.0f};
         uint32_t first_id = RTGPU_NO_HIT;
-        for (uint32_t s = 0; s < st->spp; s++) {
-          uint32_t id;
-          v3 L = trace_path(&J, x, y, st->sample_offset + s, &id, &cn);
-          if (s == 0) first_id = id;
-          sum = v3_add(sum, L);
+        for (uint32_t s0 = 0; s0 < st->spp; s0 += st->chunk_samples) {
+          v3 chunk = {0.0f, 0.0f, 0.0f};
+          uint32_t s1 = s0 + st->chunk_samples < st->spp ? s0 + st->chunk_samples : st->spp;
+          for (uint32_t s = s0; s < s1; s++) {
+            uint32_t id;
+            v3 L = trace_path(&J, x, y, st->sample_offset + s, &id, &cn);
+            if (s == 0) first_id = id;
+            chunk = v3_add(chunk, L);
+          }
+          sum = s0 == 0 ? chunk : v3_add(sum, chunk);
         }
         size_t p = (size_t)y * st->width + x;
         if (accum) {

@@ -86,7 +86,7 @@ class Settings(C.Structure):
         ("sample_offset", C.c_uint32), ("max_depth", C.c_uint32), ("seed", C.c_uint32),
         ("tmin", C.c_float), ("sky_bottom", C.c_float * 3), ("sky_top", C.c_float * 3),
         ("tile_size", C.c_uint32), ("rank", C.c_uint32), ("world_size", C.c_uint32),
-        ("flags", C.c_uint32),
+        ("flags", C.c_uint32), ("chunk_samples", C.c_uint32),
     ]
 
     def copy(self):
@@ -117,7 +117,7 @@ class FlatSceneC(C.Structure):
     ]
 
 
-assert C.sizeof(Camera) == 80 and C.sizeof(Settings) == 68 and C.sizeof(Stats) == 48
+assert C.sizeof(Camera) == 80 and C.sizeof(Settings) == 72 and C.sizeof(Stats) == 48
 
 _P = C.POINTER
 lib.rtgpu_create.argtypes = [_P(C.c_void_p), C.c_int]

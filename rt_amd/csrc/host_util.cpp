@@ -94,4 +94,5 @@ extern "C" void rtgpu_default_settings(rtgpu_settings *s, uint32_t width, uint32
   s->rank = 0;
   s->world_size = 1;
   s->flags = 0;
+  s->chunk_samples = 2;  // measured best on C2/C3 (tools/gpu_perf.py, RT_CHUNK sweep)
 }

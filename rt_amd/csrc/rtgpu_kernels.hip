@@ -48,6 +48,7 @@ struct KParams {
   float4       *accum;
   uint32_t     *prim_id;
   uint32_t     *ovf_stack;  // [kStackOvf][grid threads], see struct Stack
+  unsigned long long *wave_times;  // profile variant: {start, end, queue-dry} s_memrealtime per wave (100 MHz)
   unsigned long long *counters;  // [0] queue head, [1] paths, [2] rays, [3] nodes, [4] tris, [5] sphs, [6] scatters
   float cam_origin[3], cam_ll[3], cam_hor[3], cam_ver[3], cam_u[3], cam_v[3];
   float lens_radius;
@@ -57,8 +58,18 @@ struct KParams {
   uint32_t ts_log2, tiles_x, rank, world, n_items, flags;
   uint32_t stack_lds, stack_lds_only;
   uint32_t n_cached;  // nodes [0, n_cached) are read from the LDS copy
+  uint32_t tiles_small;  // all tile indices < 2^22: the float tile-row estimate is usable
+  float inv_tiles_x;
+  // chunked frame sums (rtgpu_settings.chunk_samples): n_chunks work items per pixel; with
+  // n_chunks > 1 chunk c of pixel slot i goes to planes[c * plane_stride + i] and
+  // combine_kernel adds the planes in order
+  float4 *planes;
+  uint32_t chunk_samples, n_chunks, plane_stride, groups_small;
+  float inv_n_chunks;
 };
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 mk2(float a, float b) { f2 r = {a, b}; return r; }
 struct V3 { float x, y, z; };
 __device__ __forceinline__ V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
 __device__ __forceinline__ V3 ld3(const float *p) { return mk(p[0], p[1], p[2]); }
@@ -81,11 +92,14 @@ __device__ __forceinline__ uint32_t pcg(uint32_t v) {
   return (w >> 22) ^ w;
 }
 
+// Draw k of a path is pcg(key + k * 0x9E3779B9); `pos` carries key + k * golden
+// incrementally (same values mod 2^32, one 32-bit multiply fewer per draw).
 struct Rng {
-  uint32_t key, ctr;
+  uint32_t pos;
+  __device__ __forceinline__ void start(uint32_t key) { pos = key; }
   __device__ __forceinline__ float u01() {
-    uint32_t h = pcg(key + ctr * 0x9E3779B9u);
-    ctr++;
+    uint32_t h = pcg(pos);
+    pos += 0x9E3779B9u;
     return (float)(h >> 8) * 0x1p-24f;
   }
 };
@@ -217,14 +231,17 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const KParams P) {
 
   // lane state
   bool done = false, alive = false, have_pixel = false, pixel_valid = false;
-  uint32_t px = 0, py = 0, out_index = 0, sample = 0, bounce = 0, first_id = RTGPU_NO_HIT;
+  uint32_t px = 0, py = 0, out_index = 0, sample = 0, sample_end = 0, chunk = 0, bounce = 0,
+           first_id = RTGPU_NO_HIT;
   V3 sum = mk(0.f, 0.f, 0.f), thr = mk(1.f, 1.f, 1.f), ro = mk(0.f, 0.f, 0.f), rd = mk(0.f, 0.f, 1.f);
-  Rng rng = {0u, 0u};
+  Rng rng = {0u};
+  V3 new_dir = mk(0.f, 0.f, 1.f);  // unnormalised direction of the segment about to start
   unsigned long long n_paths = 0, n_rays = 0, n_nodes = 0, n_tris = 0, n_sphs = 0, n_scat = 0;
   unsigned long long w_outer = 0, w_shade = 0, l_shade = 0, w_gen = 0, w_node = 0, w_sph = 0, w_tri = 0,
                      w_trav = 0, l_trav = 0;
   // traversal state (survives an early exit from the traversal loop)
   V3 inv = mk(1.f, 1.f, 1.f), noi = mk(0.f, 0.f, 0.f);
+  f2 inv_xy = mk2(1.f, 1.f), inv_zx = inv_xy, inv_yz = inv_xy, noi_xy = mk2(0.f, 0.f), noi_zx = noi_xy, noi_yz = noi_xy;
   float tbest = kTMax;
   uint32_t hit_slot = 0, cur = kDone;
   int hit_kind = 0;  // 0 none, 1 sphere, 2 triangle
@@ -250,9 +267,13 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const KParams P) {
     }
   __syncthreads();
   const float tmin = P.tmin;
+  const uint32_t seed_hash = pcg(P.seed);
   const char *const nodes_base = (const char *)P.nodes;
   const char *const tris_base = (const char *)P.tris;
   const char *const sphs_base = (const char *)P.sphs;
+
+  unsigned long long t_start = 0, t_dry = 0;
+  if (STATS == 2) t_start = __builtin_amdgcn_s_memrealtime();
 
   for (;;) {
     // ---- (1) shade the rays whose traversal has finished (rows a6, a8) ----------
@@ -333,13 +354,12 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const KParams P) {
             sd = perp + n * par;
           }
         }
-        V3 nd = normalize(sd);
         if (absorbed) {
           path_end = true;
         } else {
           thr = thr * albedo;
           ro = p;
-          rd = nd;
+          new_dir = sd;  // normalised in (3), together with fresh camera rays
           bounce++;
           if (bounce >= P.max_depth) path_end = true;  // depth exhausted: L stays 0
         }
@@ -352,16 +372,20 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const KParams P) {
     }
 
     // ---- (2) lanes without a path in flight: next sample, or next pixel ---------
-    bool need_pixel = !alive && !done && (!have_pixel || sample >= P.spp);
+    bool need_pixel = !alive && !done && (!have_pixel || sample >= sample_end);
     if (need_pixel && have_pixel) {
       if (pixel_valid) {
-        float4 o = make_float4(sum.x, sum.y, sum.z, (float)P.spp);
-        if (P.flags & RTGPU_FLAG_ACCUMULATE) {
-          float4 in = P.accum[out_index];
-          o.x = in.x + o.x; o.y = in.y + o.y; o.z = in.z + o.z; o.w = in.w + o.w;
+        if (P.n_chunks > 1u) {
+          P.planes[(size_t)chunk * P.plane_stride + out_index] = make_float4(sum.x, sum.y, sum.z, 0.0f);
+        } else {
+          float4 o = make_float4(sum.x, sum.y, sum.z, (float)P.spp);
+          if (P.flags & RTGPU_FLAG_ACCUMULATE) {
+            float4 in = P.accum[out_index];
+            o.x = in.x + o.x; o.y = in.y + o.y; o.z = in.z + o.z; o.w = in.w + o.w;
+          }
+          P.accum[out_index] = o;
         }
-        P.accum[out_index] = o;
-        if (P.prim_id) P.prim_id[out_index] = first_id;
+        if (P.prim_id && chunk == 0u) P.prim_id[out_index] = first_id;
       }
       have_pixel = false;
     }
@@ -389,7 +413,10 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const KParams P) {
         if (rank >= avail) item_lo = nb + (rank - avail);
         pool_next = nb + (cnt - avail);
         pool_end = nb + kChunk;
-        if (nb >= P.n_items) { pool_next = P.n_items; pool_end = P.n_items; }
+        if (nb >= P.n_items) {
+          pool_next = P.n_items; pool_end = P.n_items;
+          if (STATS == 2 && t_dry == 0) t_dry = __builtin_amdgcn_s_memrealtime();
+        }
       } else {
         pool_next += cnt;
       }
@@ -400,30 +427,57 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const KParams P) {
         } else {
           // item -> (local tile, 8x8 block in tile, pixel in block): lanes of a
           // wave that fetch together trace one 8x8 pixel block
-          uint32_t it = item;
+          // item -> (64-pixel group, chunk of samples): consecutive items are the 64
+          // pixels of one group for ONE chunk, groups x chunks in group-major order
+          uint32_t grp = item >> 6, pix_grp = grp;
+          chunk = 0u;
+          if (P.n_chunks > 1u) {
+            if (P.groups_small) {  // float estimate, exact below 2^22, corrected by at most one
+              pix_grp = (uint32_t)((float)grp * P.inv_n_chunks);
+              int rem = (int)(grp - pix_grp * P.n_chunks);
+              pix_grp += (rem >= (int)P.n_chunks) ? 1u : 0u;
+              pix_grp -= (rem < 0) ? 1u : 0u;
+            } else {
+              pix_grp = grp / P.n_chunks;
+            }
+            chunk = grp - pix_grp * P.n_chunks;
+          }
+          uint32_t it = (pix_grp << 6) | (item & 63u);
           uint32_t k = it & (ts * ts - 1u), j = it >> (2u * P.ts_log2);
           uint32_t blk = k >> 6, within = k & 63u;
           uint32_t tx = ((blk & ((1u << blocks_per_row_log2) - 1u)) << 3) + (within & 7u);
           uint32_t ty = ((blk >> blocks_per_row_log2) << 3) + (within >> 3);
           uint32_t tile = P.rank + j * P.world;
-          uint32_t tile_y = tile / P.tiles_x, tile_x = tile - tile_y * P.tiles_x;
+          // tile / tiles_x without the ~25-instruction integer division: a float
+          // estimate (exact operands below 2^22) corrected by at most one
+          uint32_t tile_y;
+          if (P.tiles_small) {
+            tile_y = (uint32_t)((float)tile * P.inv_tiles_x);
+            int rem = (int)(tile - tile_y * P.tiles_x);
+            tile_y += (rem >= (int)P.tiles_x) ? 1u : 0u;
+            tile_y -= (rem < 0) ? 1u : 0u;
+          } else {
+            tile_y = tile / P.tiles_x;
+          }
+          uint32_t tile_x = tile - tile_y * P.tiles_x;
           px = (tile_x << P.ts_log2) + tx;
           py = (tile_y << P.ts_log2) + ty;
           pixel_valid = px < P.width && py < P.height;
           out_index = (P.flags & RTGPU_FLAG_COMPACT) ? (j << (2u * P.ts_log2)) + (ty << P.ts_log2) + tx
                                                       : py * P.width + px;
           have_pixel = true;
-          sample = pixel_valid ? 0u : P.spp;  // out-of-image pixel: nothing to trace
+          sample = chunk * P.chunk_samples;
+          sample_end = sample + P.chunk_samples < P.spp ? sample + P.chunk_samples : P.spp;
+          if (!pixel_valid) sample = sample_end;  // out-of-image pixel: nothing to trace
           sum = mk(0.f, 0.f, 0.f);
           first_id = RTGPU_NO_HIT;
         }
       }
     }
-    if (!alive && !done && have_pixel && sample < P.spp) {
+    if (!alive && !done && have_pixel && sample < sample_end) {
       // ---- camera ray (row a1) ----
       if (STATS == 2) wave_tick(lane, w_gen);
-      rng.key = pcg((P.sample_offset + sample) ^ pcg((py * P.width + px) ^ pcg(P.seed)));
-      rng.ctr = 0;
+      rng.start(pcg((P.sample_offset + sample) ^ pcg((py * P.width + px) ^ seed_hash)));
       float jx = rng.u01(), jy = rng.u01();
       float sx = ((float)px + jx) * P.inv_w;
       float sy = ((float)py + jy) * P.inv_h;
@@ -443,7 +497,7 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const KParams P) {
         ro = cam_o + off;
         dir = dir - off;
       }
-      rd = normalize(dir);
+      new_dir = dir;  // normalised in (3)
       thr = mk(1.f, 1.f, 1.f);
       bounce = 0;
       alive = true;
@@ -453,8 +507,11 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const KParams P) {
 
     // ---- (3) start the traversal of every new segment --------------------------
     if (alive && cur == kDone) {
+      rd = normalize(new_dir);
       inv = mk(1.0f / clamp_dir(rd.x), 1.0f / clamp_dir(rd.y), 1.0f / clamp_dir(rd.z));
       noi = mk(-(ro.x * inv.x), -(ro.y * inv.y), -(ro.z * inv.z));
+      inv_xy = mk2(inv.x, inv.y); inv_zx = mk2(inv.z, inv.x); inv_yz = mk2(inv.y, inv.z);
+      noi_xy = mk2(noi.x, noi.y); noi_zx = mk2(noi.z, noi.x); noi_yz = mk2(noi.y, noi.z);
       tbest = kTMax;
       hit_kind = 0;
       cur = 0;  // root
@@ -499,14 +556,19 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const KParams P) {
             }
             if (STATS) n_nodes++;
             // child 0: lo (q0.x q0.y q0.z) hi (q0.w q1.x q1.y); child 1: lo (q1.z q1.w q2.x) hi (q2.y q2.z q2.w)
-            float a0x = __builtin_fmaf(q0.x, inv.x, noi.x), a1x = __builtin_fmaf(q0.w, inv.x, noi.x);
-            float a0y = __builtin_fmaf(q0.y, inv.y, noi.y), a1y = __builtin_fmaf(q1.x, inv.y, noi.y);
-            float a0z = __builtin_fmaf(q0.z, inv.z, noi.z), a1z = __builtin_fmaf(q1.y, inv.z, noi.z);
+            // the twelve slab fmas as six v_pk_fma_f32 (two IEEE fmas per instruction,
+            // bit-identical to fmaf): the node's planes sit in memory in the pair order
+            // (x,y)(z,x)(y,z)(x,y)(z,x)(y,z), matched by the pre-paired 1/d and -(o/d)
+            f2 p0 = __builtin_elementwise_fma(mk2(q0.x, q0.y), inv_xy, noi_xy);  // lo0.x lo0.y
+            f2 p1 = __builtin_elementwise_fma(mk2(q0.z, q0.w), inv_zx, noi_zx);  // lo0.z hi0.x
+            f2 p2 = __builtin_elementwise_fma(mk2(q1.x, q1.y), inv_yz, noi_yz);  // hi0.y hi0.z
+            f2 p3 = __builtin_elementwise_fma(mk2(q1.z, q1.w), inv_xy, noi_xy);  // lo1.x lo1.y
+            f2 p4 = __builtin_elementwise_fma(mk2(q2.x, q2.y), inv_zx, noi_zx);  // lo1.z hi1.x
+            f2 p5 = __builtin_elementwise_fma(mk2(q2.z, q2.w), inv_yz, noi_yz);  // hi1.y hi1.z
+            float a0x = p0.x, a0y = p0.y, a0z = p1.x, a1x = p1.y, a1y = p2.x, a1z = p2.y;
+            float b0x = p3.x, b0y = p3.y, b0z = p4.x, b1x = p4.y, b1y = p5.x, b1z = p5.y;
             float tn0 = fmax_(fmax_(fmin_(a0x, a1x), fmin_(a0y, a1y)), fmax_(fmin_(a0z, a1z), tmin));
             float tf0 = fmin_(fmin_(fmax_(a0x, a1x), fmax_(a0y, a1y)), fmin_(fmax_(a0z, a1z), tbest));
-            float b0x = __builtin_fmaf(q1.z, inv.x, noi.x), b1x = __builtin_fmaf(q2.y, inv.x, noi.x);
-            float b0y = __builtin_fmaf(q1.w, inv.y, noi.y), b1y = __builtin_fmaf(q2.z, inv.y, noi.y);
-            float b0z = __builtin_fmaf(q2.x, inv.z, noi.z), b1z = __builtin_fmaf(q2.w, inv.z, noi.z);
             float tn1 = fmax_(fmax_(fmin_(b0x, b1x), fmin_(b0y, b1y)), fmax_(fmin_(b0z, b1z), tmin));
             float tf1 = fmin_(fmin_(fmax_(b0x, b1x), fmax_(b0y, b1y)), fmin_(fmax_(b0z, b1z), tbest));
             uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
@@ -596,12 +658,58 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const KParams P) {
     }
   }
   if (STATS == 2) {
+    unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
+    if (lane == 0) {
+      size_t w = ((size_t)blockIdx.x * kBlock + tid) >> 6;
+      P.wave_times[w * 3 + 0] = t_start;
+      P.wave_times[w * 3 + 1] = t_end;
+      P.wave_times[w * 3 + 2] = t_dry;
+    }
     unsigned long long v[9] = {w_outer, w_shade, l_shade, w_gen, w_node, w_sph, w_tri, w_trav, l_trav};
 #pragma unroll
     for (int i = 0; i < 9; i++) {
       unsigned long long t = wave_sum(v[i]);
       if (lane == 0) atomicAdd(&P.counters[7 + i], t);
     }
+  }
+}
+
+// chunk planes -> accum: sum = C0, then += C1, += C2 ... in order (row a8).
+// Only pixels this rank owns are touched (image layout: pixels of its tiles;
+// compact layout: slots of in-image pixels), exactly the set the trace kernel wrote.
+struct CombineGeom {
+  uint32_t width, height, ts_log2, tiles_x, rank, world, compact;
+};
+__global__ __launch_bounds__(256) void combine_kernel(const float4 *planes, float4 *accum, uint64_t n,
+                                                       uint32_t n_chunks, uint64_t stride, float spp,
+                                                       uint32_t accumulate, CombineGeom g) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t step = (uint64_t)gridDim.x * blockDim.x;
+  const uint32_t mask = (1u << g.ts_log2) - 1u;
+  for (; i < n; i += step) {
+    bool mine;
+    if (g.compact) {
+      uint32_t j = (uint32_t)(i >> (2u * g.ts_log2)), ty = (uint32_t)(i >> g.ts_log2) & mask, tx = (uint32_t)i & mask;
+      uint32_t tile = g.rank + j * g.world;
+      uint32_t tile_y = tile / g.tiles_x, tile_x = tile - tile_y * g.tiles_x;
+      mine = ((tile_x << g.ts_log2) + tx) < g.width && ((tile_y << g.ts_log2) + ty) < g.height;
+    } else {
+      uint32_t y = (uint32_t)(i / g.width), x = (uint32_t)(i - (uint64_t)y * g.width);
+      uint32_t tile = (y >> g.ts_log2) * g.tiles_x + (x >> g.ts_log2);
+      mine = tile % g.world == g.rank;
+    }
+    if (!mine) continue;
+    float4 s = planes[i];
+    for (uint32_t c = 1; c < n_chunks; c++) {
+      float4 v = planes[(uint64_t)c * stride + i];
+      s.x = s.x + v.x; s.y = s.y + v.y; s.z = s.z + v.z;
+    }
+    float4 o = make_float4(s.x, s.y, s.z, spp);
+    if (accumulate) {
+      float4 in = accum[i];
+      o.x = in.x + o.x; o.y = in.y + o.y; o.z = in.z + o.z; o.w = in.w + o.w;
+    }
+    accum[i] = o;
   }
 }
 
@@ -667,6 +775,9 @@ struct rtgpu_ctx {
   bool no_node_cache = false;   // RTGPU_NO_NODE_CACHE=1: every node through the vector L1 (experiments)
   int blocks_per_cu[2] = {0, 0};
   uint32_t *d_ovf = nullptr;    // traversal-stack overflow, sized for the largest grid
+  unsigned long long *d_wave_times = nullptr;  // profile variant: 3 x u64 per wave
+  float4 *d_planes = nullptr;   // chunk planes (grow-only, zero-filled when (re)allocated)
+  size_t planes_bytes = 0;
   size_t ovf_threads = 0;
   // grow-only staging for the host-pointer entry points
   void *d_accum = nullptr;  size_t d_accum_bytes = 0;
@@ -726,6 +837,7 @@ int check_settings(rtgpu_ctx *ctx, const rtgpu_camera *cam, const rtgpu_settings
   while ((1u << l) < ts && l < 31) l++;
   if (ts < 8 || ts > 1024 || (1u << l) != ts) { ctx->err = "tile_size must be a power of two in 8..1024"; return 1; }
   if (!(s->tmin >= 0.0f)) { ctx->err = "tmin must be >= 0"; return 1; }
+  if (s->chunk_samples == 0) { ctx->err = "chunk_samples must be >= 1"; return 1; }
   *ts_log2_out = l;
   return 0;
 }
@@ -789,6 +901,11 @@ extern "C" int rtgpu_create(rtgpu_ctx **out, int device_index) {
         }
   ctx->blocks_per_cu[0] = ctx->blocks_per_cu[1] = 1;
   ctx->ovf_threads = (size_t)ctx->num_cus * kBlock;
+  if ((e = hipMalloc((void **)&ctx->d_wave_times, (size_t)ctx->num_cus * (kBlock / 64) * 3 * 8)) != hipSuccess) {
+    rtgpu::set_global_error(std::string("rtgpu_create: ") + hipGetErrorString(e));
+    rtgpu_destroy(ctx);
+    return 2;
+  }
   if (ctx->ovf_threads == 0) ctx->ovf_threads = kBlock;
   if ((e = hipMalloc((void **)&ctx->d_ovf, ctx->ovf_threads * kStackOvf * sizeof(uint32_t))) != hipSuccess) {
     rtgpu::set_global_error(std::string("rtgpu_create: overflow stack: ") + hipGetErrorString(e));
@@ -805,6 +922,8 @@ extern "C" void rtgpu_destroy(rtgpu_ctx *ctx) {
   free_scene_device(ctx);
   (void)hipFree(ctx->d_counters);
   (void)hipFree(ctx->d_ovf);
+  (void)hipFree(ctx->d_wave_times);
+  (void)hipFree(ctx->d_planes);
   (void)hipFree(ctx->d_accum);
   (void)hipFree(ctx->d_ids);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -852,8 +971,23 @@ extern "C" int rtgpu_render_device(rtgpu_ctx *ctx, const rtgpu_camera *cam, cons
 
   rtgpu::TileGrid g = rtgpu::tile_grid(s->width, s->height, s->tile_size);
   uint64_t local_tiles = rtgpu::rank_tiles(g.n_tiles, s->rank, s->world_size);
-  uint64_t n_items = local_tiles << (2 * ts_log2);
-  if (n_items >= 0xFFFFFFFFull) { ctx->err = "image too large for one launch (>= 2^32 work items)"; return 1; }
+  uint64_t n_px_items = local_tiles << (2 * ts_log2);
+  uint32_t n_chunks = (s->spp + s->chunk_samples - 1) / s->chunk_samples;
+  uint64_t n_items = n_px_items * n_chunks;
+  if (n_items >= 0xFFFFFFFFull) { ctx->err = "frame too large for one launch (>= 2^32 work items)"; return 1; }
+  uint64_t n_px_out = (s->flags & RTGPU_FLAG_COMPACT) ? n_px_items : (uint64_t)s->width * s->height;
+  if (n_chunks > 1 && n_px_out > 0) {
+    size_t want = (size_t)n_chunks * n_px_out * sizeof(float4);
+    if (ctx->planes_bytes < want) {  // grow-only
+      HIP_TRY(ctx, hipStreamSynchronize(stream));
+      (void)hipFree(ctx->d_planes);
+      ctx->d_planes = nullptr;
+      ctx->planes_bytes = 0;
+      HIP_TRY(ctx, hipMalloc((void **)&ctx->d_planes, want));
+      HIP_TRY(ctx, hipMemset(ctx->d_planes, 0, want));
+      ctx->planes_bytes = want;
+    }
+  }
 
   KParams P;
   std::memset(&P, 0, sizeof(P));
@@ -866,6 +1000,7 @@ extern "C" int rtgpu_render_device(rtgpu_ctx *ctx, const rtgpu_camera *cam, cons
   P.prim_id = (uint32_t *)d_prim_id;
   P.counters = ctx->d_counters;
   P.ovf_stack = ctx->d_ovf;
+  P.wave_times = ctx->d_wave_times;
   for (int k = 0; k < 3; k++) {
     P.cam_origin[k] = cam->origin[k]; P.cam_ll[k] = cam->lower_left[k];
     P.cam_hor[k] = cam->horizontal[k]; P.cam_ver[k] = cam->vertical[k];
@@ -880,6 +1015,12 @@ extern "C" int rtgpu_render_device(rtgpu_ctx *ctx, const rtgpu_camera *cam, cons
   P.max_depth = s->max_depth; P.seed = s->seed;
   P.ts_log2 = ts_log2; P.tiles_x = g.tiles_x; P.rank = s->rank; P.world = s->world_size;
   P.n_items = (uint32_t)n_items; P.flags = s->flags;
+  P.planes = ctx->d_planes;
+  P.chunk_samples = s->chunk_samples; P.n_chunks = n_chunks; P.plane_stride = (uint32_t)n_px_out;
+  P.groups_small = (n_items >> 6) < (1ull << 22) ? 1u : 0u;
+  P.inv_n_chunks = 1.0f / (float)n_chunks;
+  P.tiles_small = g.n_tiles < (1u << 22) ? 1u : 0u;
+  P.inv_tiles_x = 1.0f / (float)g.tiles_x;
   // LDS budget of the one block per CU: the stack gets what the tree depth
   // needs (pushes never exceed the depth; +1 sentinel, +1 for the unconditional
   // store above the top), the node cache gets the rest.
@@ -910,6 +1051,16 @@ extern "C" int rtgpu_render_device(rtgpu_ctx *ctx, const rtgpu_camera *cam, cons
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev1, stream));
     ctx->timed = true;
+    if (n_chunks > 1) {
+      uint64_t blocks = (n_px_out + 255) / 256;
+      unsigned cgrid = (unsigned)(blocks < 4096 ? blocks : 4096);
+      hipLaunchKernelGGL(combine_kernel, dim3(cgrid), dim3(256), 0, stream, (const float4 *)ctx->d_planes,
+                         (float4 *)d_accum_rgba, n_px_out, n_chunks, n_px_out, (float)s->spp,
+                         (uint32_t)((s->flags & RTGPU_FLAG_ACCUMULATE) ? 1u : 0u),
+                         CombineGeom{s->width, s->height, ts_log2, g.tiles_x, s->rank, s->world_size,
+                                     (uint32_t)((s->flags & RTGPU_FLAG_COMPACT) ? 1u : 0u)});
+      HIP_TRY(ctx, hipGetLastError());
+    }
   }
   if (stats) {
     unsigned long long c[8];
@@ -926,6 +1077,19 @@ extern "C" int rtgpu_profile_counters(rtgpu_ctx *ctx, uint64_t out[16]) {
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipDeviceSynchronize());
   HIP_TRY(ctx, hipMemcpy(out, ctx->d_counters, 128, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// Diagnostics (not in the public header): {start, end, queue-dry} 100 MHz
+// timestamps of every wave of the last RTGPU_FLAG_PROFILE launch.
+extern "C" int rtgpu_debug_wave_times(rtgpu_ctx *ctx, uint64_t *out, uint64_t max_waves, uint64_t *n_waves) {
+  if (!ctx || !out || !n_waves) return 1;
+  uint64_t n = (uint64_t)ctx->num_cus * (kBlock / 64);
+  if (n > max_waves) n = max_waves;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  HIP_TRY(ctx, hipMemcpy(out, ctx->d_wave_times, n * 3 * 8, hipMemcpyDeviceToHost));
+  *n_waves = n;
   return 0;
 }
 

@@ -180,8 +180,10 @@ def make_images(o):
     acc, ids, stats = o.render(fs.c, cam, st)
     st4 = ra.default_settings(64, 36, spp=4, max_depth=8)
     acc4, _, stats4 = o.render(fs.c, cam, st4)
+    st6 = ra.default_settings(64, 36, spp=6, max_depth=8, chunk_samples=2)   # three chunks of two
+    acc6, _, _ = o.render(fs.c, cam, st6)
     np.savez_compressed(os.path.join(HERE, "s0_64x36.npz"), ids=ids, accum_1spp=acc.view(np.uint32),
-                        accum_4spp=acc4.view(np.uint32))
+                        accum_4spp=acc4.view(np.uint32), accum_6spp_chunk2=acc6.view(np.uint32))
     # checksums of the full C1 frame (1280x720, 1 spp, depth 1 and depth 8) and counters
     scene, cam = ra.Scene.builtin(0, aspect=1280 / 720)
     fs = ra.FlatScene.build(scene)

@@ -23,10 +23,10 @@ def test_every_declared_symbol_is_exported(ra):
 
 
 def test_abi_version_and_struct_sizes(ra):
-    assert ra.lib.rtgpu_abi_version() == 1
+    assert ra.lib.rtgpu_abi_version() == 2
     from rt_amd import api
     assert C.sizeof(api.Camera) == 80
-    assert C.sizeof(api.Settings) == 68
+    assert C.sizeof(api.Settings) == 72
     assert C.sizeof(api.Stats) == 48
     assert C.sizeof(api.SceneDesc) == 48
     assert C.sizeof(api.FlatSceneC) == 88
@@ -65,6 +65,6 @@ def test_create_without_gpu_fails_cleanly(ra):
 
 def test_default_settings(ra):
     s = ra.default_settings(1920, 1080, spp=16, max_depth=8)
-    assert (s.width, s.height, s.spp, s.max_depth, s.seed, s.tile_size, s.world_size) == (1920, 1080, 16, 8, 1, 64, 1)
+    assert (s.width, s.height, s.spp, s.max_depth, s.seed, s.tile_size, s.world_size, s.chunk_samples) == (1920, 1080, 16, 8, 1, 64, 1, 2)
     assert np.float32(s.tmin) == np.float32(1e-3)
     assert list(s.sky_top) == [0.5, np.float32(0.7), 1.0] and list(s.sky_bottom) == [1.0, 1.0, 1.0]

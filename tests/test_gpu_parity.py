@@ -52,6 +52,8 @@ def test_golden_fixture_without_oracle(ra, gpu_ctx):
     a4, _, st4 = gpu_ctx.render(cam, ra.default_settings(64, 36, spp=4, max_depth=8, flags=ra.FLAG_STATS))
     assert np.array_equal(bits(a4), g["accum_4spp"])
     assert st4.as_dict() == chk["s0_64x36_stats_4spp"]
+    a6, _, _ = gpu_ctx.render(cam, ra.default_settings(64, 36, spp=6, max_depth=8, chunk_samples=2))
+    assert np.array_equal(bits(a6), g["accum_6spp_chunk2"])
     # flattened BVH bytes on this box == the ones the fixtures were made from
     fs = gpu_ctx.flat_scene()
     scene720, _ = ra.Scene.builtin(0, aspect=1280 / 720)
@@ -197,6 +199,22 @@ def test_thin_lens_and_settings(ra, oracle, gpu_ctx):
     assert np.array_equal(ia, ib)
     assert_bit_equal(a, b, "lens")
     assert sa == sb
+
+
+@pytest.mark.parametrize("spp,chunk", [(16, 4), (16, 1), (7, 3), (5, 8), (33, 2)])
+def test_chunked_frame_sum(ra, oracle, gpu_ctx, spp, chunk):
+    """Work items are (pixel, chunk of samples); chunk planes are combined in order."""
+    scene, cam = ra.Scene.builtin(0, aspect=200 / 120)
+    st = ra.default_settings(200, 120, spp=spp, max_depth=8, chunk_samples=chunk, tile_size=16)
+    (a, ia, sa), (b, ib, sb) = render_both(ra, oracle, gpu_ctx, scene, cam, st)
+    assert np.array_equal(ia, ib)
+    assert_bit_equal(a, b, f"spp {spp} chunk {chunk}")
+    assert sa == sb
+    st.flags = ra.FLAG_ACCUMULATE                       # combine honours ACCUMULATE
+    st.sample_offset = spp
+    a2, _, _ = gpu_ctx.render(cam, st, accum=a.copy())
+    b2, _, _ = oracle.render(gpu_ctx.flat_scene().c, cam, st, accum=b.copy(), threads=16)
+    assert_bit_equal(a2, b2, "accumulate")
 
 
 def test_progressive_accumulation(ra, oracle, gpu_ctx):

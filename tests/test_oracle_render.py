@@ -23,6 +23,8 @@ def test_golden_crop(ra, oracle, s0_small):
     acc4, _, stats4 = oracle.render(fs.c, cam, ra.default_settings(64, 36, spp=4, max_depth=8))
     assert np.array_equal(bits(acc4), g["accum_4spp"])
     assert stats4 == chk["s0_64x36_stats_4spp"]
+    acc6, _, _ = oracle.render(fs.c, cam, ra.default_settings(64, 36, spp=6, max_depth=8, chunk_samples=2))
+    assert np.array_equal(bits(acc6), g["accum_6spp_chunk2"])
 
 
 @pytest.mark.parametrize("depth", [1, 8])
@@ -90,6 +92,23 @@ def test_progressive_frames(ra, oracle, s0_small):
     # ...and exactly: frame sums added in order
     f2, _, _ = oracle.render(fs.c, cam, ra.default_settings(64, 36, spp=2, max_depth=8, sample_offset=2))
     assert_bit_equal(b[..., :3], a[..., :3] + f2[..., :3], "accumulate")
+
+
+def test_chunked_frame_sum(ra, oracle, s0_small):
+    """chunk_samples defines the summation tree: frame = ((C0 + C1) + C2)..., each
+    chunk the in-order sum of its samples; one chunk == plain sequential sum."""
+    _, cam, fs = s0_small
+    mk = lambda **kw: ra.default_settings(64, 36, max_depth=8, **kw)
+    whole, _, _ = oracle.render(fs.c, cam, mk(spp=5, chunk_samples=2))      # chunks {0,1} {2,3} {4}
+    parts = [oracle.render(fs.c, cam, mk(spp=n, sample_offset=o, chunk_samples=8))[0]
+             for o, n in ((0, 2), (2, 2), (4, 1))]
+    want = (parts[0][..., :3] + parts[1][..., :3]) + parts[2][..., :3]
+    assert_bit_equal(whole[..., :3], want, "chunk tree")
+    assert np.all(whole[..., 3] == 5.0)
+    seq, _, _ = oracle.render(fs.c, cam, mk(spp=5, chunk_samples=5))
+    seq2, _, _ = oracle.render(fs.c, cam, mk(spp=5, chunk_samples=99))
+    assert_bit_equal(seq, seq2, "one chunk")
+    np.testing.assert_allclose(whole, seq, rtol=1e-6, atol=1e-6)
 
 
 def test_sky_only_and_materials(ra, oracle):

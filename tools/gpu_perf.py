@@ -32,6 +32,8 @@ def main():
         fs = ctx.flat_scene()
         acc = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
         st = ra.default_settings(w, h, spp=spp, max_depth=depth, flags=ra.FLAG_STATS)
+        if os.environ.get("RT_CHUNK"):
+            st.chunk_samples = int(os.environ["RT_CHUNK"])
         stats = ra.Stats()
         ctx.render_device(cam, st, acc.data_ptr(), None, None, stats)
         s = stats.as_dict()
