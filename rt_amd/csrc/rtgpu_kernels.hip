@@ -246,6 +246,7 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const KParams P) {
   uint32_t hit_slot = 0, cur = kDone;
   int hit_kind = 0;  // 0 none, 1 sphere, 2 triangle
   unsigned pool_next = 0, pool_end = 0;  // wave-local slice of the work queue (wave-uniform)
+  bool queue_dry = false;                // wave-uniform: the global head has passed n_items
   Stack<LDS_ONLY> stk;
   stk.lds = lds_stack + tid;
   stk.ovf_stride = gridDim.x * kBlock;
@@ -404,10 +405,15 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const KParams P) {
       const unsigned avail = pool_end - pool_next;  // wave-uniform
       unsigned item_lo = pool_next + rank;
       if (cnt > avail) {                            // wave-uniform: refill
-        const unsigned leader = (unsigned)__ffsll((long long)need_mask) - 1u;
-        unsigned long long fetched = 0;
-        if (lane == leader) fetched = atomicAdd(&P.counters[0], (unsigned long long)kChunk);
-        fetched = __shfl(fetched, (int)leader, 64);
+        // once a wave has seen the queue dry it never asks again: thousands of
+        // waves polling a dry head with one atomic per iteration saturate the
+        // atomic unit and stretch the tail of the launch
+        unsigned long long fetched = (unsigned long long)P.n_items;
+        if (!queue_dry) {
+          const unsigned leader = (unsigned)__ffsll((long long)need_mask) - 1u;
+          if (lane == leader) fetched = atomicAdd(&P.counters[0], (unsigned long long)kChunk);
+          fetched = __shfl(fetched, (int)leader, 64);
+        }
         // a head beyond n_items means the queue is dry; clamp so u32 math cannot wrap
         const unsigned nb = fetched >= (unsigned long long)P.n_items ? P.n_items : (unsigned)fetched;
         if (rank >= avail) item_lo = nb + (rank - avail);
@@ -415,6 +421,7 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const KParams P) {
         pool_end = nb + kChunk;
         if (nb >= P.n_items) {
           pool_next = P.n_items; pool_end = P.n_items;
+          queue_dry = true;
           if (STATS == 2 && t_dry == 0) t_dry = __builtin_amdgcn_s_memrealtime();
         }
       } else {
