@@ -39,6 +39,25 @@ def algorithmic_flops(st):
     return 34 * st["nodes"] + 47 * st["tri_tests"] + 21 * st["sphere_tests"] + 60 * st["scatters"]
 
 
+def measured_traffic(width, height, spp, depth, world):
+    """HBM bytes per launch of the trace kernel from the PMC passes of THIS
+    workload (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in runs of their own,
+    tools/final_measure.sh; units and gfx950 correction as MI355X_MICROARCH.md
+    prescribes, calibrated on the path's own access pattern with
+    tools/ubench/fetch_calib.hip).  Counters cannot be read from inside this
+    process, so the committed summary of the last profile is reported, and only
+    when it was taken on the same workload; otherwise null."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        doc = json.load(open(path))
+    except (OSError, ValueError):
+        return None, None
+    wl = doc.get("workload", {})
+    if world != 1 or [wl.get(k) for k in ("width", "height", "spp", "depth")] != [width, height, spp, depth]:
+        return None, None
+    return int(doc["traffic_bytes_per_launch"]), doc.get("source")
+
+
 def cpu_baseline(width, height, depth, sample_spp):
     """CPU oracle on the box's host cores: the SAME scene/resolution/depth at
     `sample_spp` samples per pixel (a bounded sample of the 16-spp frame)."""
@@ -175,6 +194,7 @@ def main():
         abytes = algorithmic_bytes(counts, n_px_rank)
         aflops = algorithmic_flops(counts)
         achieved = abytes / (k_ms * 1e-3) / 1e9
+        traffic, traffic_src = measured_traffic(W, H, args.spp, depth, world)
         out = {
             "metric": "Mrays/s (whole job)", "value": round(rays_per_step * args.steps / dt / 1e6, 2),
             "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -191,8 +211,13 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                "kernel": "trace_kernel<false>", "kernel_ms": round(k_ms, 4),
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "traffic_source": traffic_src,
+                "note": "achieved counts ALGORITHMIC bytes (every node/primitive/material fetch a ray makes); "
+                        "most are served from the LDS node cache and the vector L1, so frac can exceed what "
+                        "HBM delivers - `traffic` is what actually crossed the L2's memory side; the kernel "
+                        "is bound by VALU issue and divergent-fetch latency, see `valu` and DESIGN.md",
+                "kernel": "trace_kernel<STATS=0,REFILL=16>", "kernel_ms": round(k_ms, 4),
                 "algorithmic_bytes_per_launch": int(abytes),
                 "bytes_per_ray": round(abytes / counts["rays"], 1),
                 "valu": {"achieved_tflops": round(aflops / (k_ms * 1e-3) / 1e12, 3),
