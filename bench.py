@@ -72,10 +72,17 @@ def cpu_baseline(width, height, depth, sample_spp):
     t0 = time.perf_counter()
     _, _, stats = o.render(fs.c, cam, st, threads=cores, want_ids=False)
     dt = time.perf_counter() - t0
+    # the reference program is single-threaded by design: one core, 1 spp
+    st1 = ra.default_settings(width, height, spp=1, max_depth=depth)
+    t0 = time.perf_counter()
+    _, _, stats1 = o.render(fs.c, cam, st1, threads=1, want_ids=False)
+    dt1 = time.perf_counter() - t0
     return {
         "value": round(stats["rays"] / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
         "sample": f"S0 {width}x{height}, {sample_spp} of the frame's spp, depth {depth}: "
                   f"{stats['rays']} rays in {dt:.2f} s (OpenMP over rows)",
+        "one_core": {"value": round(stats1["rays"] / dt1 / 1e6, 3), "unit": "Mrays/s", "cores": 1,
+                     "sample": f"1 spp of the same frame: {stats1['rays']} rays in {dt1:.2f} s"},
     }
 
 
@@ -88,7 +95,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=16, help="samples per pixel PER GPU (weak scaling)")
     ap.add_argument("--depth", type=int, default=8)
-    ap.add_argument("--cpu-spp", type=int, default=4, help="spp of the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--cpu-spp", type=int, default=16, help="spp of the cpu_baseline sample (0 = skip)")
     args = ap.parse_args()
 
     import torch

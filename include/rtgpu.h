@@ -118,7 +118,10 @@ typedef struct rtgpu_settings {
                             * (((C0 + C1) + C2) ...) where chunk Ck sums its samples
                             * [k*chunk_samples, min((k+1)*chunk_samples, spp)) in
                             * order.  Finer chunks = shorter tail of the persistent
-                            * kernel; the value is part of the arithmetic contract */
+                            * kernel; the value is part of the arithmetic contract.
+                            * rtgpu_default_settings: 2 up to 128 spp, else
+                            * ceil(spp / 64); n chunks > 1 cost n x 16 B per pixel
+                            * of context memory (the chunk planes) */
 } rtgpu_settings;
 
 typedef struct rtgpu_stats {

@@ -50,6 +50,8 @@ def load():
     lib.rto_kat_slab.argtypes = [f3, f3, f3, f3, C.c_float, C.c_float, f3]
     lib.rto_kat_sphere.argtypes = [f3, f3, f3, C.c_float, C.c_float, f3]
     lib.rto_kat_tri.argtypes = [f3, f3, f3, f3, f3, C.c_float, C.c_float, f3]
+    lib.rto_kat_scatter.argtypes = [C.c_uint32, C.c_float, f3, f3, C.c_uint32, C.c_uint32, f3,
+                                    C.POINTER(C.c_uint32)]
     lib.rto_render.argtypes = [
         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
         C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int]

@@ -354,6 +354,68 @@ static inline v3 reflect(v3 d, v3 n) {
   return v3_sub(d, v3_scale(n, k));
 }
 
+/* One scattering event (row a6; semantics of Shirley's "Ray Tracing in One
+ * Weekend", which the reference cites as study material, notes/materials.md:3-5).
+ * d = unit direction of the arriving ray, n = unit GEOMETRIC normal at the hit
+ * (outward for a sphere).  Returns 0 if the path is absorbed, else 1 with the
+ * unit direction of the next segment in *out.  Draws from rng exactly: lambertian
+ * and fuzzy metal one random_unit_vector; dielectric one u01 (always). */
+static inline int scatter(uint32_t type, float param, v3 d, v3 n, rng_t *rng, v3 *out) {
+  float dn = v3_dot(d, n);
+  int front = dn < 0.0f;
+  if (!front) n = v3_neg(n);
+  v3 nd;
+  if (type == RTGPU_MAT_LAMBERTIAN) {
+    v3 ruv = random_unit_vector(rng);
+    v3 sd = v3_add(n, ruv);
+    if (fabsf(sd.x) < 1e-8f && fabsf(sd.y) < 1e-8f && fabsf(sd.z) < 1e-8f) sd = n;
+    nd = v3_normalize(sd);
+  } else if (type == RTGPU_MAT_METAL) {
+    v3 rf = v3_normalize(reflect(d, n));
+    if (param > 0.0f) {
+      v3 ruv = random_unit_vector(rng);
+      rf = v3_add(rf, v3_scale(ruv, param));
+    }
+    if (!(v3_dot(rf, n) > 0.0f)) return 0;
+    nd = v3_normalize(rf);
+  } else {
+    float ri = front ? 1.0f / param : param;
+    float cos_t = fminf(-v3_dot(d, n), 1.0f);
+    float sin_t = sqrtf(1.0f - cos_t * cos_t);
+    int cannot = ri * sin_t > 1.0f;
+    float r0 = (1.0f - ri) / (1.0f + ri);
+    r0 = r0 * r0;
+    float xx = 1.0f - cos_t;
+    float x2 = xx * xx;
+    float x5 = x2 * x2 * xx;
+    float refl = r0 + (1.0f - r0) * x5;
+    float u = u01(rng); /* always drawn */
+    v3 sd;
+    if (cannot || refl > u) {
+      sd = reflect(d, n);
+    } else {
+      v3 perp = v3_scale(v3_add(d, v3_scale(n, cos_t)), ri);
+      float par = -sqrtf(fabsf(1.0f - v3_dot(perp, perp)));
+      sd = v3_add(perp, v3_scale(n, par));
+    }
+    nd = v3_normalize(sd);
+  }
+  *out = nd;
+  return 1;
+}
+
+/* Known-answer entry point for scatter(): the rng starts at draw `ctr` of `key`;
+ * draws_out = number of u01 draws consumed. */
+RTO_API int rto_kat_scatter(uint32_t type, float param, const float *d, const float *n, uint32_t key,
+                            uint32_t ctr, float *out_dir, uint32_t *draws_out) {
+  rng_t rng = {key, ctr};
+  v3 nd = {0.0f, 0.0f, 0.0f};
+  int ok = scatter(type, param, v3_from(d), v3_from(n), &rng, &nd);
+  out_dir[0] = nd.x; out_dir[1] = nd.y; out_dir[2] = nd.z;
+  if (draws_out) *draws_out = rng.ctr - ctr;
+  return ok;
+}
+
 /* ---- one path (rows a1, a6, a8) ---------------------------------------------------- */
 
 typedef struct {
@@ -430,50 +492,12 @@ static v3 trace_path(const job_t *J, uint32_t x, uint32_t y, uint32_t sample, ui
       mat = tr->material;
     }
     if (bounce == 0) *primary_id = prim;
-    float dn = v3_dot(r.d, n);
-    int front = dn < 0.0f;
-    if (!front) n = v3_neg(n);
-
     /* scatter (row a6) */
     const rtgpu_material *m = &J->sc->mats[mat];
     v3 albedo = v3_from(m->albedo);
     v3 nd;
     cn->scatters++;
-    if (m->type == RTGPU_MAT_LAMBERTIAN) {
-      v3 ruv = random_unit_vector(&rng);
-      v3 sd = v3_add(n, ruv);
-      if (fabsf(sd.x) < 1e-8f && fabsf(sd.y) < 1e-8f && fabsf(sd.z) < 1e-8f) sd = n;
-      nd = v3_normalize(sd);
-    } else if (m->type == RTGPU_MAT_METAL) {
-      v3 rf = v3_normalize(reflect(r.d, n));
-      if (m->param > 0.0f) {
-        v3 ruv = random_unit_vector(&rng);
-        rf = v3_add(rf, v3_scale(ruv, m->param));
-      }
-      if (!(v3_dot(rf, n) > 0.0f)) break; /* absorbed: L stays 0 */
-      nd = v3_normalize(rf);
-    } else {
-      float ri = front ? 1.0f / m->param : m->param;
-      float cos_t = fminf(-v3_dot(r.d, n), 1.0f);
-      float sin_t = sqrtf(1.0f - cos_t * cos_t);
-      int cannot = ri * sin_t > 1.0f;
-      float r0 = (1.0f - ri) / (1.0f + ri);
-      r0 = r0 * r0;
-      float xx = 1.0f - cos_t;
-      float x2 = xx * xx;
-      float x5 = x2 * x2 * xx;
-      float refl = r0 + (1.0f - r0) * x5;
-      float u = u01(&rng); /* always drawn */
-      v3 sd;
-      if (cannot || refl > u) {
-        sd = reflect(r.d, n);
-      } else {
-        v3 perp = v3_scale(v3_add(r.d, v3_scale(n, cos_t)), ri);
-        float par = -sqrtf(fabsf(1.0f - v3_dot(perp, perp)));
-        sd = v3_add(perp, v3_scale(n, par));
-      }
-      nd = v3_normalize(sd);
-    }
+    if (!scatter(m->type, m->param, r.d, n, &rng, &nd)) break; /* absorbed: L stays 0 */
     thr = v3_mul(thr, albedo);
     r.o = p;
     r.d = nd;

@@ -94,5 +94,8 @@ extern "C" void rtgpu_default_settings(rtgpu_settings *s, uint32_t width, uint32
   s->rank = 0;
   s->world_size = 1;
   s->flags = 0;
-  s->chunk_samples = 2;  // measured best on C2/C3 (tools/gpu_perf.py, RT_CHUNK sweep)
+  // 2 samples per work item measured best on C2/C3 (tools/gpu_perf.py, RT_CHUNK
+  // sweep); beyond 128 spp the chunks grow so that a frame never needs more than 64
+  // chunk planes (64 x 16 B per pixel of context memory)
+  s->chunk_samples = spp > 128u ? (spp + 63u) / 64u : 2u;
 }

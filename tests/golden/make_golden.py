@@ -11,7 +11,7 @@ Two kinds of fixture, kept apart on purpose:
                   of the hot path that exists in the reference (SURVEY.md §8a
                   rows a9/a10), so it is the only part that CAN be pinned by it.
 
-  rng_kat.json, isect_kat.json, s0_64x36.npz, checksums.json
+  rng_kat.json, isect_kat.json, scatter_kat.json, s0_64x36.npz, checksums.json
                   outputs of THIS repo's CPU oracle (oracle/rt_oracle.c), for
                   which the reference has no counterpart ("parity unpinned",
                   SURVEY.md §8c).  They pin the oracle against regressions and
@@ -172,6 +172,43 @@ def make_isect(o):
     print("wrote isect_kat.json")
 
 
+def scatter_cases():
+    """(type, param, d, n, key): per material, front and back faces, grazing
+    incidence, total internal reflection, fuzz that absorbs, perfect mirror."""
+    LAMB, METAL, DIEL = 0, 1, 2
+    cases = []
+    for key in (1, 0x52545F31, 0xDEADBEEF):
+        cases += [
+            (LAMB, 0.0, [0, -1, 0], [0, 1, 0], key),                    # head-on, front face
+            (LAMB, 0.0, [0.6, 0.8, 0], [0, 1, 0], key),                 # from behind: normal flips
+            (METAL, 0.0, [0.6, -0.8, 0], [0, 1, 0], key),               # perfect mirror, no draw
+            (METAL, 0.3, [0.6, -0.8, 0], [0, 1, 0], key),               # fuzzy
+            (METAL, 1.0, [0.9999, -0.01414, 0], [0, 1, 0], key),        # grazing + big fuzz: may be absorbed
+            (DIEL, 1.5, [0, -1, 0], [0, 1, 0], key),                    # entering, normal incidence
+            (DIEL, 1.5, [0.7071068, -0.7071068, 0], [0, 1, 0], key),    # entering at 45 deg
+            (DIEL, 1.5, [0.7071068, 0.7071068, 0], [0, 1, 0], key),     # leaving at 45 deg: total internal reflection
+            (DIEL, 1.5, [0.3, 0.9539392, 0], [0, 1, 0], key),           # leaving, refracts or reflects by Schlick
+            (DIEL, 1.5, [0.9999, -0.01414, 0], [0, 1, 0], key),         # grazing: reflectance near 1
+        ]
+    for key in range(2, 10):  # enough keys that some grazing fuzzy reflections end below the surface
+        cases.append((METAL, 1.0, [0.9999, -0.01414, 0], [0, 1, 0], key))
+    return cases
+
+
+def make_scatter(o):
+    import ctypes as C
+    out = np.zeros(3, np.float32)
+    doc = []
+    for (mtype, param, d, n, key) in scatter_cases():
+        d, n = norm(d), norm(n)
+        draws = C.c_uint32()
+        ok = o.lib.rto_kat_scatter(mtype, param, fptr(d), fptr(n), key, 0, fptr(out), C.byref(draws))
+        doc.append({"type": mtype, "param": bits([param])[0], "d": bits(d), "n": bits(n), "key": key,
+                    "scattered": int(ok), "dir": bits(out), "draws": int(draws.value)})
+    json.dump(doc, open(os.path.join(HERE, "scatter_kat.json"), "w"))
+    print("wrote scatter_kat.json")
+
+
 def make_images(o):
     # primary-hit id map + 1 spp radiance of a 64x36 rendering of S0 (depth 8)
     scene, cam = ra.Scene.builtin(0, aspect=64 / 36)
@@ -205,4 +242,5 @@ if __name__ == "__main__":
     make_ref_math()
     make_rng(o)
     make_isect(o)
+    make_scatter(o)
     make_images(o)

@@ -68,3 +68,7 @@ def test_default_settings(ra):
     assert (s.width, s.height, s.spp, s.max_depth, s.seed, s.tile_size, s.world_size, s.chunk_samples) == (1920, 1080, 16, 8, 1, 64, 1, 2)
     assert np.float32(s.tmin) == np.float32(1e-3)
     assert list(s.sky_top) == [0.5, np.float32(0.7), 1.0] and list(s.sky_bottom) == [1.0, 1.0, 1.0]
+    # chunk rule: 2 samples per work item up to 128 spp, then at most 64 chunks per pixel
+    for spp, want in ((1, 2), (64, 2), (128, 2), (129, 3), (256, 4), (4096, 64)):
+        st = ra.default_settings(64, 64, spp=spp)
+        assert st.chunk_samples == want and (spp + want - 1) // want <= 64

@@ -14,6 +14,8 @@ CONFIGS = {
     "c3": (1, 8, 1920, 1080, 8, 8),     # C3 is 64 spp; 8 spp here (same per-ray work)
     "c5": (2, 7, 1920, 1080, 4, 8),     # S2 at level 7 = 2.6M tris (level 8 = 10.5M)
     "c5full": (2, 8, 1920, 1080, 4, 8),
+    "c3full": (1, 8, 1920, 1080, 64, 8),   # C3 as BASELINE.json states it
+    "c4": (0, 0, 3840, 2160, 256, 8),      # C4's frame on ONE GPU (its 2/4/8-GPU runs are the driver's)
 }
 
 def main():
