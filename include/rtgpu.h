@@ -192,8 +192,10 @@ int  rtgpu_last_kernel_ms(rtgpu_ctx *ctx, float *ms);
  * execution counts {outer iterations, shade blocks, lanes in shade blocks,
  * camera-ray blocks, node steps, sphere tests, triangle tests, traversal
  * rounds, lanes in traversal rounds}: lane totals / (64 x wave counts) is the
- * SIMD lane utilisation of each section.  Synchronises the device. */
-int  rtgpu_profile_counters(rtgpu_ctx *ctx, uint64_t out[16]);
+ * SIMD lane utilisation of each section; [16..20] = shader-clock cycles summed
+ * over waves spent in {shading, work-item bookkeeping, camera rays, traversal
+ * set-up, traversal}; [21..31] zero.  Synchronises the device. */
+int  rtgpu_profile_counters(rtgpu_ctx *ctx, uint64_t out[32]);
 
 /* accum (float4 sums) -> 0xRRGGBBAA, gamma 2, like RTIOW's write_color.
  * Packing per run_tree/data/shaders/shaders.hlsl:18-25. Device pointers. */

@@ -328,7 +328,7 @@ class Context:
             C.byref(stats) if stats is not None else None))
 
     def profile_counters(self):
-        out = (C.c_uint64 * 16)()
+        out = (C.c_uint64 * 32)()
         self._check(lib.rtgpu_profile_counters(self._h, out))
         return [int(v) for v in out]
 

@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -44,9 +45,20 @@ struct BuildPrim {
 };
 
 constexpr int   kBins      = 16;
-constexpr int   kMaxLeaf   = 4;
-constexpr float kTravCost  = 1.0f;
-constexpr float kIsectCost = 1.0f;
+// SAH parameters.  Experiments may override them with RTGPU_SAH="trav,isect,maxleaf"
+// (read per build); the defaults are part of what the committed fixtures pin.
+int   kMaxLeaf   = 4;
+float kTravCost  = 1.0f;
+float kIsectCost = 1.0f;
+void read_sah_env() {
+  kMaxLeaf = 4; kTravCost = 1.0f; kIsectCost = 1.0f;
+  if (const char *e = std::getenv("RTGPU_SAH")) {
+    float t = 1.f, i = 1.f; int m = 4;
+    if (std::sscanf(e, "%f,%f,%d", &t, &i, &m) == 3 && t > 0.f && i > 0.f && m >= 1 && m <= 4) {
+      kTravCost = t; kIsectCost = i; kMaxLeaf = m;
+    }
+  }
+}
 constexpr uint32_t kMedianDepth = 40;  // below this depth: median splits only
 
 // Pad so that the fma-form slab test of the trace loop (DESIGN.md "slab test")
@@ -243,6 +255,7 @@ T *copy_out(const std::vector<T> &v, size_t min_elems = 1) {
 
 int flatten_scene(const rtgpu_scene_desc *scene, rtgpu_flat_scene *out, std::string &err) {
   std::memset(out, 0, sizeof(*out));
+  read_sah_env();
   if (!scene) { err = "scene is NULL"; return 1; }
   if ((scene->n_spheres && !scene->spheres) || (scene->n_triangles && !scene->triangles) ||
       (scene->n_materials && !scene->materials)) {
@@ -370,7 +383,21 @@ int flatten_scene(const rtgpu_scene_desc *scene, rtgpu_flat_scene *out, std::str
     return 1;
   }
 
+  // Flattened materials keep the caller's 32 bytes and use the three pad words of
+  // a dielectric for values the scatter step would otherwise divide for at every
+  // hit: 1/ior, and Schlick's r0 = ((1 - ri) / (1 + ri))^2 for ri = 1/ior (front
+  // face) and ri = ior (back face) - the same IEEE f32 operations, done once.
   std::vector<rtgpu_material> mats(scene->materials, scene->materials + scene->n_materials);
+  for (rtgpu_material &m : mats) {
+    m._pad[0] = m._pad[1] = m._pad[2] = 0u;
+    if (m.type != RTGPU_MAT_DIELECTRIC) continue;
+    volatile float ior = m.param;  // volatile: keep each operation a separate rounded f32 op
+    volatile float inv = 1.0f / ior;
+    volatile float qf = (1.0f - inv) / (1.0f + inv);
+    volatile float qb = (1.0f - ior) / (1.0f + ior);
+    float v[3] = {inv, qf * qf, qb * qb};
+    std::memcpy(m._pad, v, sizeof(v));
+  }
   // +8 zeroed records behind the leaf-ordered arrays: a leaf reference can
   // name at most 8 primitives, so even a corrupt count cannot read past them.
   out->nodes       = copy_out(B.nodes);

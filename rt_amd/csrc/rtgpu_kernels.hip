@@ -36,6 +36,7 @@ constexpr int      kStackLds   = 32;   // most entries per lane the LDS stack ma
 constexpr int      kLdsBytes   = 160 * 1024;  // LDS per CU on gfx950; one block takes all of it
 constexpr int      kStackOvf   = RTGPU_MAX_TREE_DEPTH + 2;  // global overflow entries per lane (covers stack_lds >= 2)
 constexpr uint32_t kDone       = 0xFFFFFFFFu;  // == RTGPU_REF_EMPTY, has the leaf bit
+constexpr int      kSmallNodes = 1024; // MODE 2 of the trace kernel: whole tree in LDS, planes 16 KiB apart
 constexpr unsigned kChunk      = 64;   // work items drawn per queue atomic (one 8x8 pixel block)
 constexpr float    kTMax       = 3.402823466e+38f;  // FLT_MAX: initial closest-hit distance
 
@@ -49,7 +50,7 @@ struct KParams {
   uint32_t     *prim_id;
   uint32_t     *ovf_stack;  // [kStackOvf][grid threads], see struct Stack
   unsigned long long *wave_times;  // profile variant: {start, end, queue-dry} s_memrealtime per wave (100 MHz)
-  unsigned long long *counters;  // [0] queue head, [1] paths, [2] rays, [3] nodes, [4] tris, [5] sphs, [6] scatters
+  unsigned long long *counters;  // [0] queue head, [1] paths, [2] rays, [3] nodes, [4] tris, [5] sphs, [6] scatters, [7..20] profile
   float cam_origin[3], cam_ll[3], cam_hor[3], cam_ver[3], cam_u[3], cam_v[3];
   float lens_radius;
   float inv_w, inv_h, tmin;
@@ -85,6 +86,18 @@ __device__ __forceinline__ V3 cross(V3 a, V3 b) {
 __device__ __forceinline__ V3 normalize(V3 a) { return a * (1.0f / __builtin_sqrtf(dot(a, a))); }
 __device__ __forceinline__ float fmin_(float a, float b) { return __builtin_fminf(a, b); }
 __device__ __forceinline__ float fmax_(float a, float b) { return __builtin_fmaxf(a, b); }
+// v_max_f32 / v_min_f32 as written (IEEE mode: same value as fmaxf/fminf for non-NaN
+// operands); vmax_'s second operand is wave-uniform and stays in a scalar register
+__device__ __forceinline__ float vmax_(float a, float uniform_b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "s"(uniform_b), "v"(a));
+  return r;
+}
+__device__ __forceinline__ float vmin_(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 
 __device__ __forceinline__ uint32_t pcg(uint32_t v) {
   uint32_t s = v * 747796405u + 2891336453u;
@@ -149,6 +162,7 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 template <bool LDS_ONLY>
 struct Stack {
   uint32_t *lds;        // &lds_stack[tid]
+  uint32_t *lds_m1;     // lds - kBlock: the entry below `sp` is lds_m1[sp * kBlock]
   uint32_t *ovf;        // &ovf[global thread]
   uint32_t ovf_stride;  // threads in the grid
   int lds_entries;      // entries of the LDS part in use (<= kStackLds)
@@ -165,8 +179,9 @@ struct Stack {
   // node step: push `far_c` if both children were hit, pop if none was
   __device__ __forceinline__ uint32_t step(bool both, bool none, uint32_t near_c, uint32_t far_c) {
     if (LDS_ONLY) {
-      uint32_t top = lds[(sp - 1) * kBlock];
-      lds[sp * kBlock] = far_c;
+      uint32_t *below = lds_m1 + sp * kBlock;  // one address: top at [0], free entry at [kBlock] (immediate offset)
+      uint32_t top = below[0];
+      below[kBlock] = far_c;
       sp += (both ? 1 : 0) - (none ? 1 : 0);
       return none ? top : near_c;
     }
@@ -177,7 +192,7 @@ struct Stack {
   // leaf step: pop if the leaf is exhausted
   __device__ __forceinline__ uint32_t pop_if(bool doit) {
     if (LDS_ONLY) {
-      uint32_t top = lds[(sp - 1) * kBlock];
+      uint32_t top = lds_m1[sp * kBlock];
       sp -= doit ? 1 : 0;
       return top;
     }
@@ -210,8 +225,13 @@ __device__ __forceinline__ void wave_tick(unsigned lane, unsigned long long &c) 
   if (lane == (unsigned)__ffsll((long long)m) - 1u) c++;
 }
 
-template <int STATS, int REFILL, bool LDS_ONLY>
+// MODE 0: the stack may overflow into global memory; 1: the whole stack fits in LDS;
+// 2: as 1, and the WHOLE tree (<= kSmallNodes nodes) is in the LDS node cache with its
+// four planes a compile-time distance apart, so a node fetch is one address and four
+// ds_read with immediate offsets, and no "cached or not" test.
+template <int STATS, int REFILL, int MODE>
 __global__ __launch_bounds__(kBlock) void trace_kernel(const KParams P) {
+  constexpr bool LDS_ONLY = MODE >= 1, SMALL = MODE == 2;
   // LDS: [traversal stacks: stack_lds x kBlock u32][node cache: 4 planes x n_cached float4]
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   uint32_t *const lds_stack = smem;
@@ -246,9 +266,12 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const KParams P) {
   uint32_t hit_slot = 0, cur = kDone;
   int hit_kind = 0;  // 0 none, 1 sphere, 2 triangle
   unsigned pool_next = 0, pool_end = 0;  // wave-local slice of the work queue (wave-uniform)
+  // wave-uniform description of the group the pool was drawn from (see (2))
+  uint32_t g_px = 0, g_py = 0, g_out = 0, g_row = 0, g_chunk = 0, g_sample = 0, g_sample_end = 0;
   bool queue_dry = false;                // wave-uniform: the global head has passed n_items
   Stack<LDS_ONLY> stk;
   stk.lds = lds_stack + tid;
+  stk.lds_m1 = lds_stack + tid - kBlock;  // never dereferenced below sp = 1
   stk.ovf_stride = gridDim.x * kBlock;
   stk.ovf = P.ovf_stack + (size_t)blockIdx.x * kBlock + tid;
   stk.sp = 1;
@@ -260,12 +283,12 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const KParams P) {
   // consecutive 16-byte bank groups (measured 56 cycles per 64-lane node fetch
   // vs 142 for node-major LDS and 181 through the vector L1, tools/ubench).
   const uint32_t n_cached = P.n_cached;
-  for (uint32_t i = tid; i < n_cached * 4u; i += kBlock)
-  {
-      float4 v = P.nodes[i];
-      f4 w = {v.x, v.y, v.z, v.w};
-      node_cache[(i & 3u) * n_cached + (i >> 2)] = w;
-    }
+  const uint32_t plane = SMALL ? (uint32_t)kSmallNodes : n_cached;  // nodes per plane
+  for (uint32_t i = tid; i < n_cached * 4u; i += kBlock) {
+    float4 v = P.nodes[i];
+    f4 w = {v.x, v.y, v.z, v.w};
+    node_cache[(i & 3u) * plane + (i >> 2)] = w;
+  }
   __syncthreads();
   const float tmin = P.tmin;
   const uint32_t seed_hash = pcg(P.seed);
@@ -275,6 +298,10 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const KParams P) {
 
   unsigned long long t_start = 0, t_dry = 0;
   if (STATS == 2) t_start = __builtin_amdgcn_s_memrealtime();
+  // profile build: shader-clock cycles this wave spent per section of the outer loop
+  long long c_shade = 0, c_item = 0, c_gen = 0, c_setup = 0, c_trav = 0, c_mark = 0;
+#define SECTION_END(acc) do { if (STATS == 2) { long long t_ = (long long)clock64(); acc += t_ - c_mark; c_mark = t_; } } while (0)
+  if (STATS == 2) c_mark = (long long)clock64();
 
   for (;;) {
     // ---- (1) shade the rays whose traversal has finished (rows a6, a8) ----------
@@ -336,12 +363,13 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const KParams P) {
           if (param > 0.0f) sd = sd + ruv * param;
           absorbed = !(dot(sd, n) > 0.0f);
         } else {
-          float ri = front ? 1.0f / param : param;
+          // 1/ior and Schlick's r0 per face come precomputed with the flattened
+          // material (bvh_build.cpp): the same f32 operations, done once on the host
+          float ri = front ? m1.y : param;
           float cos_t = fmin_(-dot(rd, n), 1.0f);
           float sin_t = __builtin_sqrtf(1.0f - cos_t * cos_t);
           bool cannot = ri * sin_t > 1.0f;
-          float r0 = (1.0f - ri) / (1.0f + ri);
-          r0 = r0 * r0;
+          float r0 = front ? m1.z : m1.w;
           float xx = 1.0f - cos_t;
           float x2 = xx * xx;
           float x5 = x2 * x2 * xx;
@@ -372,6 +400,7 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const KParams P) {
       }
     }
 
+    SECTION_END(c_shade);
     // ---- (2) lanes without a path in flight: next sample, or next pixel ---------
     bool need_pixel = !alive && !done && (!have_pixel || sample >= sample_end);
     if (need_pixel && have_pixel) {
@@ -390,97 +419,106 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const KParams P) {
       }
       have_pixel = false;
     }
+    // Work queue: the global head is one word, and a returning atomic on one word
+    // saturates near 88 per microsecond chip-wide (MI355X_MICROARCH.md, row
+    // "dequeue") - one atomic per finished pixel made the queue, not the tracing,
+    // the bottleneck of the 1080p frame.  So a wave draws a GROUP of kChunk items
+    // per atomic: the 64 pixels of one 8x8 block for one chunk of samples.  All
+    // that differs between the items of a group is the pixel's place in the block,
+    // so the item -> (tile, block, chunk, sample range, output slot) arithmetic is
+    // done once per group on wave-uniform values (g_*, scalar registers) and a lane
+    // that takes an item only adds its (x, y) in the block.  Needy lanes take items
+    // by their rank among the needy lanes (ballot + mbcnt prefix); when the group
+    // runs out mid-wave the loop below goes round once more with a fresh group.
     unsigned long long need_mask = __ballot(need_pixel);
-    if (need_mask != 0ull) {  // wave-uniform
-      // Work queue: the global head is one word, and a returning atomic on one
-      // word saturates near 88 per microsecond chip-wide (MI355X_MICROARCH.md,
-      // row "dequeue") - one atomic per finished pixel made the queue, not the
-      // tracing, the bottleneck of the 1080p frame.  So a wave draws kChunk items
-      // (one 8x8 pixel block) per atomic into a wave-local pool [pool_next,
-      // pool_end) and its lanes take from the pool by their rank among the needy
-      // lanes (ballot + mbcnt prefix): one atomic per 64 pixels.
-      const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(need_mask >> 32),
-                                                      __builtin_amdgcn_mbcnt_lo((unsigned)need_mask, 0u));
-      const unsigned cnt = (unsigned)__builtin_popcountll(need_mask);
-      const unsigned avail = pool_end - pool_next;  // wave-uniform
-      unsigned item_lo = pool_next + rank;
-      if (cnt > avail) {                            // wave-uniform: refill
+    while (need_mask != 0ull) {  // wave-uniform, at most two rounds
+      if (pool_next == pool_end) {  // wave-uniform: draw the next group
         // once a wave has seen the queue dry it never asks again: thousands of
         // waves polling a dry head with one atomic per iteration saturate the
         // atomic unit and stretch the tail of the launch
-        unsigned long long fetched = (unsigned long long)P.n_items;
+        unsigned nb = P.n_items;
         if (!queue_dry) {
           const unsigned leader = (unsigned)__ffsll((long long)need_mask) - 1u;
+          unsigned long long fetched = 0ull;
           if (lane == leader) fetched = atomicAdd(&P.counters[0], (unsigned long long)kChunk);
           fetched = __shfl(fetched, (int)leader, 64);
+          // a head beyond n_items means the queue is dry; clamp so u32 math cannot wrap
+          nb = fetched >= (unsigned long long)P.n_items ? P.n_items : (unsigned)fetched;
+          nb = (unsigned)__builtin_amdgcn_readfirstlane((int)nb);
         }
-        // a head beyond n_items means the queue is dry; clamp so u32 math cannot wrap
-        const unsigned nb = fetched >= (unsigned long long)P.n_items ? P.n_items : (unsigned)fetched;
-        if (rank >= avail) item_lo = nb + (rank - avail);
-        pool_next = nb + (cnt - avail);
-        pool_end = nb + kChunk;
         if (nb >= P.n_items) {
-          pool_next = P.n_items; pool_end = P.n_items;
           queue_dry = true;
           if (STATS == 2 && t_dry == 0) t_dry = __builtin_amdgcn_s_memrealtime();
+          if (need_pixel) done = true;
+          break;
         }
-      } else {
-        pool_next += cnt;
-      }
-      if (need_pixel) {
-        const unsigned item = item_lo;
-        if (item >= P.n_items) {
-          done = true;
-        } else {
-          // item -> (local tile, 8x8 block in tile, pixel in block): lanes of a
-          // wave that fetch together trace one 8x8 pixel block
-          // item -> (64-pixel group, chunk of samples): consecutive items are the 64
-          // pixels of one group for ONE chunk, groups x chunks in group-major order
-          uint32_t grp = item >> 6, pix_grp = grp;
-          chunk = 0u;
-          if (P.n_chunks > 1u) {
-            if (P.groups_small) {  // float estimate, exact below 2^22, corrected by at most one
-              pix_grp = (uint32_t)((float)grp * P.inv_n_chunks);
-              int rem = (int)(grp - pix_grp * P.n_chunks);
-              pix_grp += (rem >= (int)P.n_chunks) ? 1u : 0u;
-              pix_grp -= (rem < 0) ? 1u : 0u;
-            } else {
-              pix_grp = grp / P.n_chunks;
-            }
-            chunk = grp - pix_grp * P.n_chunks;
-          }
-          uint32_t it = (pix_grp << 6) | (item & 63u);
-          uint32_t k = it & (ts * ts - 1u), j = it >> (2u * P.ts_log2);
-          uint32_t blk = k >> 6, within = k & 63u;
-          uint32_t tx = ((blk & ((1u << blocks_per_row_log2) - 1u)) << 3) + (within & 7u);
-          uint32_t ty = ((blk >> blocks_per_row_log2) << 3) + (within >> 3);
-          uint32_t tile = P.rank + j * P.world;
-          // tile / tiles_x without the ~25-instruction integer division: a float
-          // estimate (exact operands below 2^22) corrected by at most one
-          uint32_t tile_y;
-          if (P.tiles_small) {
-            tile_y = (uint32_t)((float)tile * P.inv_tiles_x);
-            int rem = (int)(tile - tile_y * P.tiles_x);
-            tile_y += (rem >= (int)P.tiles_x) ? 1u : 0u;
-            tile_y -= (rem < 0) ? 1u : 0u;
+        pool_next = nb;
+        pool_end = nb + kChunk;  // n_items is a multiple of kChunk
+        // group -> (64-pixel group, chunk of samples): groups x chunks, pixel-group-major
+        uint32_t grp = nb >> 6, pix_grp = grp, chunk_u = 0u;
+        if (P.n_chunks > 1u) {
+          if (P.groups_small) {  // float estimate, exact below 2^22, corrected by at most one
+            pix_grp = (uint32_t)((float)grp * P.inv_n_chunks);
+            int rem = (int)(grp - pix_grp * P.n_chunks);
+            pix_grp += (rem >= (int)P.n_chunks) ? 1u : 0u;
+            pix_grp -= (rem < 0) ? 1u : 0u;
           } else {
-            tile_y = tile / P.tiles_x;
+            pix_grp = grp / P.n_chunks;
           }
-          uint32_t tile_x = tile - tile_y * P.tiles_x;
-          px = (tile_x << P.ts_log2) + tx;
-          py = (tile_y << P.ts_log2) + ty;
-          pixel_valid = px < P.width && py < P.height;
-          out_index = (P.flags & RTGPU_FLAG_COMPACT) ? (j << (2u * P.ts_log2)) + (ty << P.ts_log2) + tx
-                                                      : py * P.width + px;
-          have_pixel = true;
-          sample = chunk * P.chunk_samples;
-          sample_end = sample + P.chunk_samples < P.spp ? sample + P.chunk_samples : P.spp;
-          if (!pixel_valid) sample = sample_end;  // out-of-image pixel: nothing to trace
-          sum = mk(0.f, 0.f, 0.f);
-          first_id = RTGPU_NO_HIT;
+          pix_grp = (uint32_t)__builtin_amdgcn_readfirstlane((int)pix_grp);
+          chunk_u = grp - pix_grp * P.n_chunks;
         }
+        // pixel group -> (local tile j, 8x8 block in the tile)
+        const uint32_t it = pix_grp << 6;
+        const uint32_t k = it & (ts * ts - 1u), j = it >> (2u * P.ts_log2);
+        const uint32_t blk = k >> 6;
+        const uint32_t tx = (blk & ((1u << blocks_per_row_log2) - 1u)) << 3;
+        const uint32_t ty = (blk >> blocks_per_row_log2) << 3;
+        const uint32_t tile = P.rank + j * P.world;
+        // tile / tiles_x without the integer division: a float estimate (exact
+        // operands below 2^22) corrected by at most one
+        uint32_t tile_y;
+        if (P.tiles_small) {
+          tile_y = (uint32_t)((float)tile * P.inv_tiles_x);
+          int rem = (int)(tile - tile_y * P.tiles_x);
+          tile_y += (rem >= (int)P.tiles_x) ? 1u : 0u;
+          tile_y -= (rem < 0) ? 1u : 0u;
+        } else {
+          tile_y = tile / P.tiles_x;
+        }
+        tile_y = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile_y);
+        const uint32_t tile_x = tile - tile_y * P.tiles_x;
+        g_px = (tile_x << P.ts_log2) + tx;
+        g_py = (tile_y << P.ts_log2) + ty;
+        g_row = (P.flags & RTGPU_FLAG_COMPACT) ? ts : P.width;  // output slots per image row
+        g_out = (P.flags & RTGPU_FLAG_COMPACT) ? (j << (2u * P.ts_log2)) + (ty << P.ts_log2) + tx
+                                                : g_py * P.width + g_px;
+        g_chunk = chunk_u;
+        g_sample = chunk_u * P.chunk_samples;
+        g_sample_end = g_sample + P.chunk_samples < P.spp ? g_sample + P.chunk_samples : P.spp;
       }
+      const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(need_mask >> 32),
+                                                      __builtin_amdgcn_mbcnt_lo((unsigned)need_mask, 0u));
+      const unsigned cnt = (unsigned)__builtin_popcountll(need_mask);
+      const unsigned avail = pool_end - pool_next;  // wave-uniform, >= 1
+      if (need_pixel && rank < avail) {
+        const uint32_t within = (pool_next + rank) & 63u, wx = within & 7u, wy = within >> 3;
+        px = g_px + wx;
+        py = g_py + wy;
+        pixel_valid = px < P.width && py < P.height;
+        out_index = g_out + wy * g_row + wx;
+        chunk = g_chunk;
+        have_pixel = true;
+        sample = pixel_valid ? g_sample : g_sample_end;  // out-of-image pixel: nothing to trace
+        sample_end = g_sample_end;
+        sum = mk(0.f, 0.f, 0.f);
+        first_id = RTGPU_NO_HIT;
+        need_pixel = false;
+      }
+      pool_next += cnt < avail ? cnt : avail;
+      need_mask = __ballot(need_pixel);
     }
+    SECTION_END(c_item);
     if (!alive && !done && have_pixel && sample < sample_end) {
       // ---- camera ray (row a1) ----
       if (STATS == 2) wave_tick(lane, w_gen);
@@ -510,6 +548,7 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const KParams P) {
       alive = true;
       n_paths++;
     }
+    SECTION_END(c_gen);
     if (__ballot(alive) == 0ull) break;  // done implies !alive: the whole wave is dry
 
     // ---- (3) start the traversal of every new segment --------------------------
@@ -526,6 +565,7 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const KParams P) {
       n_rays++;
     }
 
+    SECTION_END(c_setup);
     // ---- (4) closest hit: ordered stack traversal (rows a3-a5) ------------------
     // Every lane walks its own ray in the oracle's order; what the WAVE executes
     // next is put to a vote between the lanes waiting at an inner node and the
@@ -550,9 +590,9 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const KParams P) {
           if ((int)cur >= 0) {
             if (STATS == 2) wave_tick(lane, w_node);
             float4 q0, q1, q2, q3;
-            if (cur < n_cached) {
-              f4 w0 = node_cache[cur], w1 = node_cache[n_cached + cur], w2 = node_cache[2u * n_cached + cur],
-                 w3 = node_cache[3u * n_cached + cur];
+            if (SMALL || cur < n_cached) {
+              f4 w0 = node_cache[cur], w1 = node_cache[plane + cur], w2 = node_cache[2u * plane + cur],
+                 w3 = node_cache[3u * plane + cur];
               q0 = make_float4(w0.x, w0.y, w0.z, w0.w);
               q1 = make_float4(w1.x, w1.y, w1.z, w1.w);
               q2 = make_float4(w2.x, w2.y, w2.z, w2.w);
@@ -574,10 +614,13 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const KParams P) {
             f2 p5 = __builtin_elementwise_fma(mk2(q2.z, q2.w), inv_yz, noi_yz);  // hi1.y hi1.z
             float a0x = p0.x, a0y = p0.y, a0z = p1.x, a1x = p1.y, a1y = p2.x, a1z = p2.y;
             float b0x = p3.x, b0y = p3.y, b0z = p4.x, b1x = p4.y, b1y = p5.x, b1z = p5.y;
-            float tn0 = fmax_(fmax_(fmin_(a0x, a1x), fmin_(a0y, a1y)), fmax_(fmin_(a0z, a1z), tmin));
-            float tf0 = fmin_(fmin_(fmax_(a0x, a1x), fmax_(a0y, a1y)), fmin_(fmax_(a0z, a1z), tbest));
-            float tn1 = fmax_(fmax_(fmin_(b0x, b1x), fmin_(b0y, b1y)), fmax_(fmin_(b0z, b1z), tmin));
-            float tf1 = fmin_(fmin_(fmax_(b0x, b1x), fmax_(b0y, b1y)), fmin_(fmax_(b0z, b1z), tbest));
+            // vmax_/vmin_: the bare instruction for the two operands that hipcc cannot
+            // prove canonical (tmin from the kernel arguments, tbest through the loop):
+            // the builtin costs an extra v_max x,x per operand per step
+            float tn0 = fmax_(fmax_(fmin_(a0x, a1x), fmin_(a0y, a1y)), vmax_(fmin_(a0z, a1z), tmin));
+            float tf0 = fmin_(fmin_(fmax_(a0x, a1x), fmax_(a0y, a1y)), vmin_(fmax_(a0z, a1z), tbest));
+            float tn1 = fmax_(fmax_(fmin_(b0x, b1x), fmin_(b0y, b1y)), vmax_(fmin_(b0z, b1z), tmin));
+            float tf1 = fmin_(fmin_(fmax_(b0x, b1x), fmax_(b0y, b1y)), vmin_(fmax_(b0z, b1z), tbest));
             uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
             // an empty child (scenes of < 2 primitives) has its box at +inf and can
             // never pass: tfar <= tbest <= FLT_MAX < tnear
@@ -643,7 +686,9 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const KParams P) {
         } while (n_leaf > 0 && 2 * n_leaf > n_trav);
       }
     }
+    SECTION_END(c_trav);
   }
+#undef SECTION_END
 
   // ---- counters: one atomic per wave and counter --------------------------------
   n_paths = wave_sum(n_paths);
@@ -677,6 +722,13 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const KParams P) {
     for (int i = 0; i < 9; i++) {
       unsigned long long t = wave_sum(v[i]);
       if (lane == 0) atomicAdd(&P.counters[7 + i], t);
+    }
+    if (lane == 0) {
+      atomicAdd(&P.counters[16], (unsigned long long)c_shade);
+      atomicAdd(&P.counters[17], (unsigned long long)c_item);
+      atomicAdd(&P.counters[18], (unsigned long long)c_gen);
+      atomicAdd(&P.counters[19], (unsigned long long)c_setup);
+      atomicAdd(&P.counters[20], (unsigned long long)c_trav);
     }
   }
 }
@@ -795,14 +847,14 @@ namespace {
 
 // Kernel variants: {refill threshold} x {plain, instrumented}.  One source, one
 // code path; the threshold only changes WHEN finished lanes are refilled, never
-// what a path computes.  RTGPU_REFILL (0/16/32/48) selects it for experiments.
+// what a path computes.  RTGPU_REFILL (0/16) selects it for experiments.
 using KernelFn = void (*)(const KParams);
-struct Variant { int refill; KernelFn fn[3][2]; };  // [plain, stats, profile][overflow-capable, LDS-only]
+struct Variant { int refill; KernelFn fn[3][3]; };  // [plain, stats, profile][MODE 0, 1, 2 of trace_kernel]
 #define RTGPU_VARIANT(R)                                                                   \
-  {R, {{trace_kernel<0, R, false>, trace_kernel<0, R, true>},                               \
-       {trace_kernel<1, R, false>, trace_kernel<1, R, true>},                               \
-       {trace_kernel<2, R, false>, trace_kernel<2, R, true>}}}
-const Variant kVariants[] = {RTGPU_VARIANT(0), RTGPU_VARIANT(16), RTGPU_VARIANT(32)};
+  {R, {{trace_kernel<0, R, 0>, trace_kernel<0, R, 1>, trace_kernel<0, R, 2>},               \
+       {trace_kernel<1, R, 0>, trace_kernel<1, R, 1>, trace_kernel<1, R, 2>},               \
+       {trace_kernel<2, R, 0>, trace_kernel<2, R, 1>, trace_kernel<2, R, 2>}}}
+const Variant kVariants[] = {RTGPU_VARIANT(0), RTGPU_VARIANT(16)};
 constexpr int kDefaultVariant = 1;  // refill below 16 traversing lanes (measured best on C2/C3/C5)
 
 bool hip_fail(rtgpu_ctx *ctx, hipError_t e, const char *what) {
@@ -873,7 +925,7 @@ extern "C" int rtgpu_create(rtgpu_ctx **out, int device_index) {
   hipDeviceProp_t prop;
   if ((e = hipSetDevice(device_index)) != hipSuccess ||
       (e = hipGetDeviceProperties(&prop, device_index)) != hipSuccess ||
-      (e = hipMalloc((void **)&ctx->d_counters, 128)) != hipSuccess ||
+      (e = hipMalloc((void **)&ctx->d_counters, 256)) != hipSuccess ||
       (e = hipEventCreate(&ctx->ev0)) != hipSuccess || (e = hipEventCreate(&ctx->ev1)) != hipSuccess) {
     rtgpu::set_global_error(std::string("rtgpu_create: ") + hipGetErrorString(e));
     rtgpu_destroy(ctx);
@@ -899,7 +951,7 @@ extern "C" int rtgpu_create(rtgpu_ctx **out, int device_index) {
   // one 1024-thread block per CU, holding all 160 KiB of its LDS
   for (const Variant &v : kVariants)
     for (int a = 0; a < 3; a++)
-      for (int b = 0; b < 2; b++)
+      for (int b = 0; b < 3; b++)
         if ((e = hipFuncSetAttribute((const void *)v.fn[a][b], hipFuncAttributeMaxDynamicSharedMemorySize,
                                      kLdsBytes)) != hipSuccess) {
           rtgpu::set_global_error(std::string("rtgpu_create: LDS attribute: ") + hipGetErrorString(e));
@@ -1042,9 +1094,17 @@ extern "C" int rtgpu_render_device(rtgpu_ctx *ctx, const rtgpu_camera *cam, cons
   P.n_cached = (uint32_t)(fit < top ? fit : top);
   if (ctx->no_node_cache) P.n_cached = 0;
   size_t lds_bytes = (size_t)stack_lds * kBlock * sizeof(uint32_t) + (size_t)P.n_cached * sizeof(rtgpu_node);
+  // small scenes: the whole tree in LDS with planes kSmallNodes apart (MODE 2)
+  int mode = P.stack_lds_only ? 1 : 0;
+  if (mode == 1 && !ctx->no_node_cache && ctx->host.n_nodes <= (uint64_t)kSmallNodes &&
+      P.n_cached == ctx->host.n_nodes &&
+      (size_t)stack_lds * kBlock * sizeof(uint32_t) + (size_t)kSmallNodes * sizeof(rtgpu_node) <= (size_t)kLdsBytes) {
+    mode = 2;
+    lds_bytes = (size_t)stack_lds * kBlock * sizeof(uint32_t) + (size_t)kSmallNodes * sizeof(rtgpu_node);
+  }
 
   bool want_stats = (s->flags & (RTGPU_FLAG_STATS | RTGPU_FLAG_PROFILE)) != 0;
-  HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 128, stream));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 256, stream));
   ctx->timed = false;
   if (n_items > 0) {
     uint64_t want = (n_items + kBlock - 1) / kBlock;
@@ -1053,7 +1113,7 @@ extern "C" int rtgpu_render_device(rtgpu_ctx *ctx, const rtgpu_camera *cam, cons
     if ((size_t)grid * kBlock > ctx->ovf_threads) { ctx->err = "internal: grid exceeds the overflow stack"; return 2; }
     const Variant &var = kVariants[ctx->variant];
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
-    KernelFn fn = var.fn[(s->flags & RTGPU_FLAG_PROFILE) ? 2 : want_stats ? 1 : 0][P.stack_lds_only ? 1 : 0];
+    KernelFn fn = var.fn[(s->flags & RTGPU_FLAG_PROFILE) ? 2 : want_stats ? 1 : 0][mode];
     hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), lds_bytes, stream, P);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev1, stream));
@@ -1079,11 +1139,11 @@ extern "C" int rtgpu_render_device(rtgpu_ctx *ctx, const rtgpu_camera *cam, cons
   return 0;
 }
 
-extern "C" int rtgpu_profile_counters(rtgpu_ctx *ctx, uint64_t out[16]) {
+extern "C" int rtgpu_profile_counters(rtgpu_ctx *ctx, uint64_t out[32]) {
   if (!ctx || !out) return 1;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipDeviceSynchronize());
-  HIP_TRY(ctx, hipMemcpy(out, ctx->d_counters, 128, hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpy(out, ctx->d_counters, 256, hipMemcpyDeviceToHost));
   return 0;
 }
 

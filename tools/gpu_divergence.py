@@ -13,10 +13,13 @@ for name in sys.argv[1:] or ["c2", "c3", "c5"]:
     st = ra.default_settings(w, h, spp=spp, max_depth=depth, flags=ra.FLAG_PROFILE)
     ctx.render_device(cam, st, acc.data_ptr(), None, None)
     c = ctx.profile_counters()
-    _, paths, rays, nodes, tris, sphs, scat, w_outer, w_shade, l_shade, w_gen, w_node, w_sph, w_tri, w_trav, l_trav = c
+    _, paths, rays, nodes, tris, sphs, scat, w_outer, w_shade, l_shade, w_gen, w_node, w_sph, w_tri, w_trav, l_trav = c[:16]
+    cyc = c[16:21]
     u = lambda l, wv: l / (64.0 * wv) if wv else float("nan")
     print(f"{name}: rays={rays} | wave-level counts per 64 rays: outer={w_outer*64/rays:.2f} shade={w_shade*64/rays:.2f} "
           f"gen={w_gen*64/rays:.2f} node={w_node*64/rays:.1f} sph={w_sph*64/rays:.2f} tri={w_tri*64/rays:.2f} trav_rounds={w_trav*64/rays:.2f}\n"
           f"   lane utilisation: shade={u(l_shade, w_shade):.3f} gen={u(paths, w_gen):.3f} node={u(nodes, w_node):.3f} "
-          f"sph={u(sphs, w_sph):.3f} tri={u(tris, w_tri):.3f} trav_round={u(l_trav, w_trav):.3f}", flush=True)
+          f"sph={u(sphs, w_sph):.3f} tri={u(tris, w_tri):.3f} trav_round={u(l_trav, w_trav):.3f}\n"
+          f"   wave time share: " + " ".join(f"{n}={v / max(1, sum(cyc)):.3f}" for n, v in
+                                           zip(("shade", "item", "gen", "setup", "traversal"), cyc)), flush=True)
 ctx.close()
