@@ -5,8 +5,9 @@
 // Conventions followed: POD arrays, zero-initialised long-lived allocations as
 // alloc_perm does (code/base/memory.cxx:23-34), f32 arithmetic only.
 //
-// Determinism: single-threaded, no data-dependent container ordering, so the
-// same scene always flattens to the same bytes (the oracle walks these bytes).
+// Determinism: no data-dependent container ordering and a thread-count-independent
+// task decomposition (struct Builder), so the same scene always flattens to the
+// same bytes (the oracle walks these bytes).
 #include "rtgpu_internal.h"
 
 #include <algorithm>
@@ -15,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 namespace rtgpu {
@@ -72,33 +74,45 @@ inline void pad_box(Box &b) {
   }
 }
 
+// One builder per flatten call.  The leaf-ordered primitive arrays are sized up
+// front and written by position: leaves are numbered left to right, so the slice
+// a subtree writes is known from the number of spheres / triangles left of it.
+// Nodes are numbered depth-first, which is NOT known up front, so every subtree
+// is built into its own vector with subtree-local indices and stitched into its
+// parent's ([parent][left subtree][right subtree]).  Large subtrees near the
+// root run as parallel tasks; the bytes produced do not depend on the number of
+// threads (each task only touches its own range of `prims` and its own slices).
 struct Builder {
   const rtgpu_scene_desc *scene;
   std::vector<BuildPrim>  prims;
-  std::vector<rtgpu_node> nodes;
-  std::vector<rtgpu_tri>  tris;
-  std::vector<rtgpu_sph>  sphs;
-  std::vector<uint32_t>   sph_meta;
-  uint32_t                max_depth = 0;
+  std::vector<rtgpu_tri>  tris;      // sized n_triangles
+  std::vector<rtgpu_sph>  sphs;      // sized n_spheres
+  std::vector<uint32_t>   sph_meta;  // sized 2 * n_spheres
 
-  uint32_t make_leaf(size_t b, size_t e, uint32_t depth) {
-    max_depth = std::max(max_depth, depth);
+  struct Sub {                       // one subtree under construction
+    std::vector<rtgpu_node> nodes;   // subtree-local indices; node 0 is its root (if it has inner nodes)
+    uint32_t max_depth = 0;
+    size_t   tri_at = 0, sph_at = 0; // next free slot of this subtree's leaf slices
+  };
+
+  uint32_t make_leaf(Sub &S, size_t b, size_t e, uint32_t depth) {
+    S.max_depth = std::max(S.max_depth, depth);
     uint32_t n = (uint32_t)(e - b);
     bool sph = prims[b].is_sphere != 0;
     uint32_t first;
     if (sph) {
-      first = (uint32_t)sphs.size();
-      for (size_t i = b; i < e; i++) {
+      first = (uint32_t)S.sph_at;
+      for (size_t i = b; i < e; i++, S.sph_at++) {
         const rtgpu_sphere &s = scene->spheres[prims[i].index];
         rtgpu_sph r;
         r.c[0] = s.center[0]; r.c[1] = s.center[1]; r.c[2] = s.center[2]; r.r = s.radius;
-        sphs.push_back(r);
-        sph_meta.push_back(prims[i].index);  // prim id: spheres come first
-        sph_meta.push_back(s.material);
+        sphs[S.sph_at] = r;
+        sph_meta[2 * S.sph_at]     = prims[i].index;  // prim id: spheres come first
+        sph_meta[2 * S.sph_at + 1] = s.material;
       }
     } else {
-      first = (uint32_t)tris.size();
-      for (size_t i = b; i < e; i++) {
+      first = (uint32_t)S.tri_at;
+      for (size_t i = b; i < e; i++, S.tri_at++) {
         const rtgpu_triangle &t = scene->triangles[prims[i].index];
         rtgpu_tri r;
         for (int k = 0; k < 3; k++) {
@@ -109,29 +123,57 @@ struct Builder {
         r.prim_id  = (uint32_t)scene->n_spheres + prims[i].index;
         r.material = t.material;
         r._pad     = 0;
-        tris.push_back(r);
+        tris[S.tri_at] = r;
       }
     }
     return RTGPU_REF_LEAF | (sph ? RTGPU_REF_SPHERE : 0u) | ((n - 1u) << 27) | first;
   }
 
-  // Returns the child reference for prims[b, e) and its bounds.
-  uint32_t build(size_t b, size_t e, uint32_t depth, Box &bounds) {
+  // fn(chunk_begin, chunk_end, t) over T equal chunks of [b, e), chunk t on its own thread
+  static constexpr size_t kParScanMin = 1u << 18;
+  static constexpr int    kParScanThreads = 8;
+  template <typename F>
+  static void chunked(size_t b, size_t e, int T, F fn) {
+    if (T <= 1) { fn(b, e, 0); return; }
+    std::vector<std::thread> th;
+    size_t n = e - b;
+    for (int t = 1; t < T; t++) th.emplace_back(fn, b + n * (size_t)t / (size_t)T, b + n * (size_t)(t + 1) / (size_t)T, t);
+    fn(b, b + n / (size_t)T, 0);
+    for (auto &x : th) x.join();
+  }
+
+  // Bounds of prims[b, e) and the split decision: false = make a leaf, true =
+  // children are prims[b, mid) and prims[mid, e) (the range is partitioned in place).
+  bool choose_split(size_t b, size_t e, uint32_t depth, Box &bounds, size_t &mid) {
     size_t n = e - b;
     Box cb;
     bounds.reset();
     cb.reset();
     size_t n_sph = 0;
-    for (size_t i = b; i < e; i++) {
-      bounds.grow(prims[i].box);
-      cb.grow(prims[i].c, prims[i].c);
-      n_sph += prims[i].is_sphere;
+    // ranges near the root are scanned by several threads; min/max and counts are
+    // exact, so the merged result does not depend on the chunking
+    const int T = n >= kParScanMin ? kParScanThreads : 1;
+    {
+      Box tb[kParScanThreads], tcb[kParScanThreads];
+      size_t ts[kParScanThreads];
+      chunked(b, e, T, [&](size_t cb_, size_t ce_, int t) {
+        Box bb, cc;
+        bb.reset(); cc.reset();
+        size_t ns = 0;
+        for (size_t i = cb_; i < ce_; i++) {
+          bb.grow(prims[i].box);
+          cc.grow(prims[i].c, prims[i].c);
+          ns += prims[i].is_sphere;
+        }
+        tb[t] = bb; tcb[t] = cc; ts[t] = ns;
+      });
+      for (int t = 0; t < T; t++) { bounds.grow(tb[t]); cb.grow(tcb[t]); n_sph += ts[t]; }
     }
     bool mixed = n_sph != 0 && n_sph != n;
-    if (n == 1) return make_leaf(b, e, depth);
+    if (n == 1) return false;
 
-    size_t mid = 0;
-    bool   have_split = false;
+    mid = 0;
+    bool have_split = false;
 
     if (mixed && n <= (size_t)kMaxLeaf) {
       // small mixed cluster: split by type so each leaf holds one type
@@ -146,18 +188,34 @@ struct Builder {
       float best_cost = INFINITY;
       int   best_axis = -1, best_bin = -1;
       float parent_area = bounds.half_area();
+      // one pass over the range fills the bins of all three axes
+      struct Bins { Box box[3][kBins]; size_t cnt[3][kBins]; };
+      std::vector<Bins> tbins((size_t)T);
+      float scale3[3];
       for (int axis = 0; axis < 3; axis++) {
-        float lo = cb.lo[axis], ext = cb.hi[axis] - cb.lo[axis];
+        float ext = cb.hi[axis] - cb.lo[axis];
+        scale3[axis] = ext > 0.f ? (float)kBins / ext : 0.f;
+      }
+      chunked(b, e, T, [&](size_t cb_, size_t ce_, int t) {
+        Bins &B = tbins[(size_t)t];
+        for (int axis = 0; axis < 3; axis++)
+          for (int i = 0; i < kBins; i++) { B.box[axis][i].reset(); B.cnt[axis][i] = 0; }
+        for (size_t i = cb_; i < ce_; i++)
+          for (int axis = 0; axis < 3; axis++) {
+            int bi = (int)((prims[i].c[axis] - cb.lo[axis]) * scale3[axis]);
+            bi = std::min(std::max(bi, 0), kBins - 1);
+            B.box[axis][bi].grow(prims[i].box);
+            B.cnt[axis][bi]++;
+          }
+      });
+      for (int axis = 0; axis < 3; axis++) {
+        float ext = cb.hi[axis] - cb.lo[axis];
         if (!(ext > 0.f)) continue;
-        float scale = (float)kBins / ext;
         Box   bin_box[kBins];
         size_t bin_cnt[kBins];
-        for (int i = 0; i < kBins; i++) { bin_box[i].reset(); bin_cnt[i] = 0; }
-        for (size_t i = b; i < e; i++) {
-          int bi = (int)((prims[i].c[axis] - lo) * scale);
-          bi = std::min(std::max(bi, 0), kBins - 1);
-          bin_box[bi].grow(prims[i].box);
-          bin_cnt[bi]++;
+        for (int i = 0; i < kBins; i++) {
+          bin_box[i].reset(); bin_cnt[i] = 0;
+          for (int t = 0; t < T; t++) { bin_box[i].grow(tbins[(size_t)t].box[axis][i]); bin_cnt[i] += tbins[(size_t)t].cnt[axis][i]; }
         }
         float  right_area[kBins];
         size_t right_cnt[kBins];
@@ -183,8 +241,7 @@ struct Builder {
       if (best_axis >= 0) {
         float split_cost = kTravCost + kIsectCost * best_cost / std::max(parent_area, 1e-30f);
         float leaf_cost  = kIsectCost * (float)n;
-        if (n <= (size_t)kMaxLeaf && !mixed && leaf_cost <= split_cost)
-          return make_leaf(b, e, depth);
+        if (n <= (size_t)kMaxLeaf && !mixed && leaf_cost <= split_cost) return false;
         float lo = cb.lo[best_axis], ext = cb.hi[best_axis] - cb.lo[best_axis];
         float scale = (float)kBins / ext;
         auto it = std::stable_partition(
@@ -199,7 +256,7 @@ struct Builder {
     }
 
     if (!have_split) {
-      if (n <= (size_t)kMaxLeaf && !mixed) return make_leaf(b, e, depth);
+      if (n <= (size_t)kMaxLeaf && !mixed) return false;
       // median split along the widest centroid axis (also the depth-bounded path)
       int axis = 0;
       float best = -1.f;
@@ -221,13 +278,10 @@ struct Builder {
                          });
       }
     }
+    return true;
+  }
 
-    uint32_t me = (uint32_t)nodes.size();
-    nodes.emplace_back();
-    Box b0, b1;
-    uint32_t c0 = build(b, mid, depth + 1, b0);
-    uint32_t c1 = build(mid, e, depth + 1, b1);
-    rtgpu_node &nd = nodes[me];
+  static void set_children(rtgpu_node &nd, const Box &b0, const Box &b1, uint32_t c0, uint32_t c1) {
     for (int k = 0; k < 3; k++) {
       nd.lo0[k] = b0.lo[k]; nd.hi0[k] = b0.hi[k];
       nd.lo1[k] = b1.lo[k]; nd.hi1[k] = b1.hi[k];
@@ -235,6 +289,59 @@ struct Builder {
     nd.child0 = c0;
     nd.child1 = c1;
     nd._pad[0] = nd._pad[1] = 0;
+  }
+
+  // Sequential depth-first build of prims[b, e) into S: returns the child reference
+  // (an S-local node index, or a leaf reference) and the bounds.
+  uint32_t build(Sub &S, size_t b, size_t e, uint32_t depth, Box &bounds) {
+    size_t mid;
+    if (!choose_split(b, e, depth, bounds, mid)) return make_leaf(S, b, e, depth);
+    uint32_t me = (uint32_t)S.nodes.size();
+    S.nodes.emplace_back();
+    Box b0, b1;
+    uint32_t c0 = build(S, b, mid, depth + 1, b0);
+    uint32_t c1 = build(S, mid, e, depth + 1, b1);
+    set_children(S.nodes[me], b0, b1, c0, c1);
+    return me;
+  }
+
+  // Task-parallel build of a large range: the two children are built as separate
+  // Subs (the left one on another thread) and stitched behind this node.
+  static constexpr size_t   kTaskMinPrims = 1u << 16;
+  uint32_t task_depth = 6;  // at most 64 leaf tasks; RTGPU_BUILD_TASK_DEPTH=0 builds on one thread
+  uint32_t build_tasks(Sub &S, size_t b, size_t e, uint32_t depth, Box &bounds) {
+    if (e - b < kTaskMinPrims || depth >= task_depth) return build(S, b, e, depth, bounds);
+    size_t mid;
+    if (!choose_split(b, e, depth, bounds, mid)) return make_leaf(S, b, e, depth);
+    size_t left_sph = 0;
+    for (size_t i = b; i < mid; i++) left_sph += prims[i].is_sphere;
+    Sub L, R;
+    L.sph_at = S.sph_at;             L.tri_at = S.tri_at;
+    R.sph_at = S.sph_at + left_sph;  R.tri_at = S.tri_at + ((mid - b) - left_sph);
+    Box b0, b1;
+    uint32_t c0 = 0, c1 = 0;
+    std::thread left([&] { c0 = build_tasks(L, b, mid, depth + 1, b0); });
+    c1 = build_tasks(R, mid, e, depth + 1, b1);
+    left.join();
+    S.sph_at = R.sph_at;
+    S.tri_at = R.tri_at;
+    S.max_depth = std::max(S.max_depth, std::max(L.max_depth, R.max_depth));
+    // stitch: [me][L.nodes][R.nodes], inner references shifted to S-local indices
+    uint32_t me = (uint32_t)S.nodes.size();
+    uint32_t l_at = me + 1u, r_at = l_at + (uint32_t)L.nodes.size();
+    S.nodes.emplace_back();
+    auto append = [&](const Sub &C, uint32_t at) {
+      for (rtgpu_node nd : C.nodes) {
+        if (!(nd.child0 & RTGPU_REF_LEAF)) nd.child0 += at;
+        if (!(nd.child1 & RTGPU_REF_LEAF)) nd.child1 += at;
+        S.nodes.push_back(nd);
+      }
+    };
+    append(L, l_at);
+    append(R, r_at);
+    if (!(c0 & RTGPU_REF_LEAF)) c0 += l_at;
+    if (!(c1 & RTGPU_REF_LEAF)) c1 += r_at;
+    set_children(S.nodes[me], b0, b1, c0, c1);
     return me;
   }
 };
@@ -274,6 +381,10 @@ int flatten_scene(const rtgpu_scene_desc *scene, rtgpu_flat_scene *out, std::str
 
   Builder B;
   B.scene = scene;
+  if (const char *e = std::getenv("RTGPU_BUILD_TASK_DEPTH")) {
+    int d = std::atoi(e);
+    if (d >= 0 && d <= 8) B.task_depth = (uint32_t)d;
+  }
   B.prims.reserve(scene->n_spheres + scene->n_triangles);
   for (uint64_t i = 0; i < scene->n_spheres; i++) {
     const rtgpu_sphere &s = scene->spheres[i];
@@ -314,10 +425,11 @@ int flatten_scene(const rtgpu_scene_desc *scene, rtgpu_flat_scene *out, std::str
   }
 
   size_t n = B.prims.size();
-  B.nodes.reserve(n ? n : 1);
-  B.tris.reserve(scene->n_triangles);
-  B.sphs.reserve(scene->n_spheres);
-  B.sph_meta.reserve(scene->n_spheres * 2);
+  B.tris.resize(scene->n_triangles);
+  B.sphs.resize(scene->n_spheres);
+  B.sph_meta.resize(scene->n_spheres * 2);
+  Builder::Sub top;
+  top.nodes.reserve(n ? n : 1);
 
   // Empty child: a box at +inf.  Its slab interval is [+inf,+inf] or [-inf,-inf]
   // on every axis, and the closest-hit distance starts at FLT_MAX, so it can
@@ -333,28 +445,33 @@ int flatten_scene(const rtgpu_scene_desc *scene, rtgpu_flat_scene *out, std::str
     root.child0 = root.child1 = RTGPU_REF_EMPTY;
     if (n == 1) {
       for (int k = 0; k < 3; k++) { root.lo0[k] = B.prims[0].box.lo[k]; root.hi0[k] = B.prims[0].box.hi[k]; }
-      root.child0 = B.make_leaf(0, 1, 1);
+      root.child0 = B.make_leaf(top, 0, 1, 1);
     }
-    B.nodes.push_back(root);
+    top.nodes.push_back(root);
   } else {
     Box bounds;
-    uint32_t r = B.build(0, n, 0, bounds);
+    uint32_t r = B.build_tasks(top, 0, n, 0, bounds);
     if (r != 0) { err = "internal: root is not node 0"; return 1; }
   }
+  if (top.tri_at != B.tris.size() || top.sph_at != B.sphs.size()) {
+    err = "internal: leaf arrays not filled";
+    return 1;
+  }
+  std::vector<rtgpu_node> &nodes = top.nodes;
   // Node order: the builder emits depth-first (a subtree is contiguous, which
   // keeps deep traversal steps within few cache lines); the first
   // RTGPU_TOP_NODES nodes are then re-numbered breadth-first, so that "index <
   // K" means "one of the K nodes nearest the root" - the part of the tree every
   // ray walks, which the kernel keeps in LDS.  Pure renumbering: boxes, child
   // order and therefore every traversal are unchanged.
-  if (B.nodes.size() > 2) {
-    const size_t nn = B.nodes.size();
+  if (nodes.size() > 2) {
+    const size_t nn = nodes.size();
     std::vector<uint32_t> new_of_old(nn, 0xFFFFFFFFu), order;
     order.reserve(nn);
     order.push_back(0);
     new_of_old[0] = 0;
     for (size_t head = 0; head < order.size() && order.size() < RTGPU_TOP_NODES; head++) {
-      const rtgpu_node &nd = B.nodes[order[head]];
+      const rtgpu_node &nd = nodes[order[head]];
       const uint32_t ch[2] = {nd.child0, nd.child1};
       for (uint32_t c : ch)
         if (!(c & RTGPU_REF_LEAF) && order.size() < RTGPU_TOP_NODES) {
@@ -366,19 +483,19 @@ int flatten_scene(const rtgpu_scene_desc *scene, rtgpu_flat_scene *out, std::str
       if (new_of_old[i] == 0xFFFFFFFFu) { new_of_old[i] = (uint32_t)order.size(); order.push_back((uint32_t)i); }
     std::vector<rtgpu_node> re(nn);
     for (size_t k = 0; k < nn; k++) {
-      rtgpu_node nd = B.nodes[order[k]];
+      rtgpu_node nd = nodes[order[k]];
       if (!(nd.child0 & RTGPU_REF_LEAF)) nd.child0 = new_of_old[nd.child0];
       if (!(nd.child1 & RTGPU_REF_LEAF)) nd.child1 = new_of_old[nd.child1];
       re[k] = nd;
     }
-    B.nodes.swap(re);
+    nodes.swap(re);
   }
 
-  if (B.nodes.size() * sizeof(rtgpu_node) >= (1ull << 32) || B.tris.size() * sizeof(rtgpu_tri) >= (1ull << 32)) {
+  if (nodes.size() * sizeof(rtgpu_node) >= (1ull << 32) || B.tris.size() * sizeof(rtgpu_tri) >= (1ull << 32)) {
     err = "scene too large: node or triangle buffer would reach 4 GiB (the kernel uses 32-bit offsets)";
     return 1;
   }
-  if (B.max_depth > RTGPU_MAX_TREE_DEPTH) {
+  if (top.max_depth > RTGPU_MAX_TREE_DEPTH) {
     err = "internal: BVH deeper than RTGPU_MAX_TREE_DEPTH";
     return 1;
   }
@@ -400,8 +517,8 @@ int flatten_scene(const rtgpu_scene_desc *scene, rtgpu_flat_scene *out, std::str
   }
   // +8 zeroed records behind the leaf-ordered arrays: a leaf reference can
   // name at most 8 primitives, so even a corrupt count cannot read past them.
-  out->nodes       = copy_out(B.nodes);
-  out->n_nodes     = B.nodes.size();
+  out->nodes       = copy_out(nodes);
+  out->n_nodes     = nodes.size();
   out->tris        = copy_out(B.tris, B.tris.size() + 8);
   out->n_tris      = B.tris.size();
   out->spheres     = copy_out(B.sphs, B.sphs.size() + 8);
@@ -409,7 +526,7 @@ int flatten_scene(const rtgpu_scene_desc *scene, rtgpu_flat_scene *out, std::str
   out->sphere_meta = copy_out(B.sph_meta, B.sph_meta.size() + 16);
   out->materials   = copy_out(mats);
   out->n_materials = mats.size();
-  out->max_depth   = B.max_depth;
+  out->max_depth   = top.max_depth;
   if (!out->nodes || !out->tris || !out->spheres || !out->sphere_meta || !out->materials) {
     free_flat_scene(out);
     err = "out of host memory while flattening the scene";

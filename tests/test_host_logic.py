@@ -19,6 +19,23 @@ def test_flatten_is_deterministic_and_pinned(ra):
     assert fnv1a_words(a.nodes_u32) == g["nodes_fnv"]
 
 
+def test_parallel_build_is_thread_count_independent(ra, oracle, monkeypatch):
+    """Large scenes are built by parallel tasks near the root (Builder::build_tasks)
+    and threaded scans; the flattened bytes must not depend on that."""
+    scene, _ = ra.Scene.builtin(1, param=7)   # 327,682 prims: task splits and threaded scans both engage
+    monkeypatch.setenv("RTGPU_BUILD_TASK_DEPTH", "0")
+    one = ra.FlatScene.build(scene)
+    monkeypatch.setenv("RTGPU_BUILD_TASK_DEPTH", "6")
+    many = ra.FlatScene.build(scene)
+    monkeypatch.setenv("RTGPU_BUILD_TASK_DEPTH", "2")
+    few = ra.FlatScene.build(scene)
+    for other in (many, few):
+        assert np.array_equal(one.nodes_u32, other.nodes_u32) and np.array_equal(one.tris_u32, other.tris_u32)
+        assert one.c.max_depth == other.c.max_depth
+    rc, depth = oracle.validate_bvh(many.c)
+    assert rc == 0 and depth == many.c.max_depth
+
+
 @pytest.mark.parametrize("kind,param", [(0, 0), (1, 3), (1, 6), (2, 3)])
 def test_bvh_is_structurally_valid(ra, oracle, kind, param):
     scene, _ = ra.Scene.builtin(kind, param=param)
