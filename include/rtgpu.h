@@ -233,6 +233,25 @@ int  rtgpu_scene_builtin(uint32_t kind, uint32_t seed, uint32_t param,
                          rtgpu_scene_desc *out, rtgpu_camera *cam_out, float aspect);
 void rtgpu_scene_free(rtgpu_scene_desc *scene);
 
+/* ---- data formats either side of the loop --------
+ * No reference counterpart ("3D models" is a plan item, notes/plan.md:21);
+ * whole-file I/O in the manner of code/os/filesystem.hxx:4-9.
+ *
+ * Wavefront OBJ text -> triangles.  `v x y z`, `f` with v, v/vt, v//vn or
+ * v/vt/vn tokens, 1-based or negative (relative) indices, polygons fanned
+ * around their first vertex, `usemtl NAME`; other records are skipped.
+ * materials[0] = grey lambertian (faces before any usemtl), materials[1..] =
+ * one grey lambertian per usemtl name in order of first appearance; the
+ * arrays are malloc'ed and the caller's to edit; free with rtgpu_scene_free.
+ * Errors (bad index, non-finite vertex, short face, I/O) -> non-zero +
+ * rtgpu_last_error(NULL). */
+int  rtgpu_scene_parse_obj(const char *text, uint64_t n_bytes, rtgpu_scene_desc *out);
+int  rtgpu_scene_load_obj(const char *path, rtgpu_scene_desc *out);
+
+/* Resolved frame (0xRRGGBBAA, row 0 = bottom, as rtgpu_resolve_rgba8 writes it)
+ * -> binary PPM (P6), rows flipped to top-down, alpha dropped. */
+int  rtgpu_write_ppm(const char *path, const uint32_t *rgba8, uint32_t width, uint32_t height);
+
 #ifdef __cplusplus
 }
 #endif

@@ -152,6 +152,9 @@ lib.rtgpu_default_settings.restype = None
 lib.rtgpu_scene_builtin.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, _P(SceneDesc), _P(Camera), C.c_float]
 lib.rtgpu_scene_free.argtypes = [_P(SceneDesc)]
 lib.rtgpu_scene_free.restype = None
+lib.rtgpu_scene_parse_obj.argtypes = [C.c_char_p, C.c_uint64, _P(SceneDesc)]
+lib.rtgpu_scene_load_obj.argtypes = [C.c_char_p, _P(SceneDesc)]
+lib.rtgpu_write_ppm.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32]
 
 
 def _global_error():
@@ -174,6 +177,14 @@ def default_settings(width, height, spp=1, max_depth=8, **kw):
         else:
             setattr(s, k, v)
     return s
+
+
+def write_ppm(path, rgba8):
+    """rgba8: uint32 [h, w] of 0xRRGGBBAA, row 0 = bottom (what Context.resolve returns)."""
+    a = np.ascontiguousarray(rgba8, np.uint32)
+    h, w = a.shape
+    if lib.rtgpu_write_ppm(str(path).encode(), a.ctypes.data, w, h):
+        raise RtgpuError(_global_error())
 
 
 def compact_pixels(width, height, tile_size, rank, world):
@@ -200,23 +211,40 @@ class Scene:
         return len(self.spheres) + len(self.triangles)
 
     @staticmethod
-    def builtin(kind, seed=SCENE_SEED, param=0, aspect=16 / 9):
-        """S0/S1/S2 of SURVEY.md §8d -> (Scene, Camera).  Arrays are copied into numpy."""
-        d, cam = SceneDesc(), Camera()
-        if lib.rtgpu_scene_builtin(kind, seed, param, C.byref(d), C.byref(cam), aspect):
-            raise RtgpuError(_global_error())
+    def _from_desc(d):
+        """Copies the malloc'ed arrays of a library-made descriptor into numpy and frees them."""
         try:
             def grab(ptr, n, dt):
                 if not n:
                     return np.zeros(0, dt)
                 buf = (C.c_char * (n * dt.itemsize)).from_address(ptr)
                 return np.frombuffer(buf, dtype=dt).copy()
-            sc = Scene(grab(d.spheres, d.n_spheres, SPHERE_DTYPE),
-                       grab(d.triangles, d.n_triangles, TRIANGLE_DTYPE),
-                       grab(d.materials, d.n_materials, MATERIAL_DTYPE))
+            return Scene(grab(d.spheres, d.n_spheres, SPHERE_DTYPE),
+                         grab(d.triangles, d.n_triangles, TRIANGLE_DTYPE),
+                         grab(d.materials, d.n_materials, MATERIAL_DTYPE))
         finally:
             lib.rtgpu_scene_free(C.byref(d))
-        return sc, cam
+
+    @staticmethod
+    def builtin(kind, seed=SCENE_SEED, param=0, aspect=16 / 9):
+        """S0/S1/S2 of SURVEY.md §8d -> (Scene, Camera).  Arrays are copied into numpy."""
+        d, cam = SceneDesc(), Camera()
+        if lib.rtgpu_scene_builtin(kind, seed, param, C.byref(d), C.byref(cam), aspect):
+            raise RtgpuError(_global_error())
+        return Scene._from_desc(d), cam
+
+    @staticmethod
+    def from_obj(path=None, text=None):
+        """Wavefront OBJ file or text -> Scene of triangles (rtgpu_scene_load_obj / _parse_obj)."""
+        d = SceneDesc()
+        if text is not None:
+            raw = text.encode() if isinstance(text, str) else bytes(text)
+            rc = lib.rtgpu_scene_parse_obj(raw, len(raw), C.byref(d))
+        else:
+            rc = lib.rtgpu_scene_load_obj(str(path).encode(), C.byref(d))
+        if rc:
+            raise RtgpuError(_global_error())
+        return Scene._from_desc(d)
 
 
 class FlatScene:

@@ -53,6 +53,27 @@ void rt_resolve_rgba8_or_panic(Vec4 const *accum, u32 *rgba8_out, s64 pixel_coun
     errf("rt: resolve failed: %s", ::rtgpu_last_error(gRt_Ctx));
 }
 
+Scene rt_scene_load_obj_or_panic(char const *path) {
+  ::rtgpu_scene_desc d = {};
+  if (::rtgpu_scene_load_obj(path, &d) != 0) errf("rt: %s", ::rtgpu_last_error(nullptr));
+  return Scene{(Sphere *)d.spheres,     (s64)d.n_spheres,
+               (Triangle *)d.triangles, (s64)d.n_triangles,
+               (Material *)d.materials, (s64)d.n_materials};
+}
+
+void rt_scene_free(Scene &scene) {
+  ::rtgpu_scene_desc d = {};
+  d.spheres = (::rtgpu_sphere const *)scene.spheres;
+  d.triangles = (::rtgpu_triangle const *)scene.triangles;
+  d.materials = (::rtgpu_material const *)scene.materials;
+  ::rtgpu_scene_free(&d);
+  scene = Scene{};
+}
+
+void rt_write_ppm_or_panic(char const *path, u32 const *rgba8, u32 width, u32 height) {
+  if (::rtgpu_write_ppm(path, rgba8, width, height) != 0) errf("rt: %s", ::rtgpu_last_error(nullptr));
+}
+
 f32 rt_last_kernel_ms() {
   f32 ms = 0.f;
   if (::rtgpu_last_kernel_ms(gRt_Ctx, &ms) != 0) return -1.f;

@@ -92,4 +92,13 @@ void rt_render_or_panic(Camera const &cam, Render_Settings const &settings, Vec4
 void rt_resolve_rgba8_or_panic(Vec4 const *accum, u32 *rgba8_out, s64 pixel_count);
 
 [[nodiscard]] f32 rt_last_kernel_ms();
+
+// Data formats either side of the loop, whole-file
+// like os_read_entire_file / os_write_entire_file_or_panic
+// (code/os/filesystem.hxx:4-9).  A loaded Scene owns malloc'ed arrays: release
+// with rt_scene_free (or keep it for the process lifetime, alloc_perm style).
+[[nodiscard]] Scene rt_scene_load_obj_or_panic(char const *path);
+void rt_scene_free(Scene &scene);
+// rgba8: 0xRRGGBBAA, row 0 = bottom (what rt_resolve_rgba8_or_panic writes)
+void rt_write_ppm_or_panic(char const *path, u32 const *rgba8, u32 width, u32 height);
 }  // namespace rt

@@ -2,7 +2,9 @@
 // (code/first.cpp cannot be built off Windows): the same
 // init chain and "frame loop" shape, with a PPM file where Present would be.
 //
-//   rt_headless [scene 0|1|2] [width height spp depth level out.ppm]
+//   rt_headless [scene 0|1|2 | mesh.obj] [width height spp depth level out.ppm]
+// A scene argument that is not a number is read as a Wavefront OBJ file and
+// framed from its bounding box.
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -35,15 +37,43 @@ int main(int argc, char **argv) {
   u32 level  = argc > 6 ? (u32)std::atoi(argv[6]) : 6;
   char const *out_path = argc > 7 ? argv[7] : "rt_headless.ppm";
 
+  bool from_file = argc > 1 && (argv[1][0] < '0' || argv[1][0] > '9');
+
   rt_init_or_panic();
 
-  ::rtgpu_scene_desc builtin;
+  ::rtgpu_scene_desc builtin = {};
   Camera cam;
-  if (::rtgpu_scene_builtin(kind, 0x52545F31u, level, &builtin, &cam, (f32)width / (f32)height) != 0)
-    errf("builtin scene: %s", ::rtgpu_last_error(nullptr));
-  Scene scene = {(Sphere *)builtin.spheres,     (s64)builtin.n_spheres,
-                 (Triangle *)builtin.triangles, (s64)builtin.n_triangles,
-                 (Material *)builtin.materials, (s64)builtin.n_materials};
+  Scene scene;
+  if (from_file) {
+    scene = rt_scene_load_obj_or_panic(argv[1]);
+    if (scene.triangles_count == 0) errf("%s holds no faces", argv[1]);
+    Vec3 lo = scene.triangles[0].v0, hi = lo;
+    for (s64 i = 0; i < scene.triangles_count; i++) {
+      Vec3 const *v[3] = {&scene.triangles[i].v0, &scene.triangles[i].v1, &scene.triangles[i].v2};
+      for (auto p : v)
+        for (int k = 0; k < 3; k++) {
+          if (p->v[k] < lo.v[k]) lo.v[k] = p->v[k];
+          if (p->v[k] > hi.v[k]) hi.v[k] = p->v[k];
+        }
+    }
+    Vec3 mid, from;
+    f32 r = 0.f;
+    for (int k = 0; k < 3; k++) {
+      mid.v[k] = 0.5f * (lo.v[k] + hi.v[k]);
+      if (hi.v[k] - lo.v[k] > r) r = hi.v[k] - lo.v[k];
+    }
+    from.x = mid.x + 1.2f * r; from.y = mid.y + 0.8f * r; from.z = mid.z + 1.6f * r;
+    Vec3 up; up.x = 0.f; up.y = 1.f; up.z = 0.f;
+    cam = rt_camera_look_at(from, mid, up, 40.f, (f32)width / (f32)height);
+    builtin.n_spheres = 0;
+    builtin.n_triangles = (uint64_t)scene.triangles_count;
+  } else {
+    if (::rtgpu_scene_builtin(kind, 0x52545F31u, level, &builtin, &cam, (f32)width / (f32)height) != 0)
+      errf("builtin scene: %s", ::rtgpu_last_error(nullptr));
+    scene = Scene{(Sphere *)builtin.spheres,     (s64)builtin.n_spheres,
+                  (Triangle *)builtin.triangles, (s64)builtin.n_triangles,
+                  (Material *)builtin.materials, (s64)builtin.n_materials};
+  }
   rt_scene_upload_or_panic(scene);
 
   // alloc_perm-style: zeroed, lives until exit (code/base/memory.cxx:23-34)
@@ -65,18 +95,9 @@ int main(int argc, char **argv) {
               (unsigned long long)stats.rays, rt_last_kernel_ms(),
               (double)stats.rays / (rt_last_kernel_ms() * 1e3), ms);
 
-  std::FILE *f = std::fopen(out_path, "wb");
-  if (!f) errf("cannot open %s", out_path);
-  std::fprintf(f, "P6 %u %u 255\n", width, height);
-  for (u32 y = height; y-- > 0;)  // row 0 is the bottom row (code/math/mat.cxx:104-129)
-    for (u32 x = 0; x < width; x++) {
-      u32 c = rgba[(size_t)y * width + x];  // 0xRRGGBBAA (code/gfx/gfx.hpp:4-6)
-      u8 px[3] = {(u8)(c >> 24), (u8)(c >> 16), (u8)(c >> 8)};
-      std::fwrite(px, 1, 3, f);
-    }
-  std::fclose(f);
+  rt_write_ppm_or_panic(out_path, rgba, width, height);  // where Present would be
   std::printf("wrote %s\n", out_path);
-  ::rtgpu_scene_free(&builtin);
+  rt_scene_free(scene);
   rt_shutdown();
   return 0;
 }
