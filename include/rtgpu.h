@@ -161,6 +161,15 @@ uint32_t rtgpu_abi_version(void);
 /* Builds the BVH on the host, flattens scene + BVH into SoA node/primitive
  * buffers and copies them to HBM. */
 int  rtgpu_upload_scene(rtgpu_ctx *ctx, const rtgpu_scene_desc *scene);
+
+/* SURVEY.md §8f row 3 (no reference counterpart): as rtgpu_upload_scene, but the
+ * BVH is built on the GPU - Morton codes, one radix sort, Karras' parallel
+ * hierarchy (HPG 2012), level-by-level box fit - straight into the same
+ * flattened format, one primitive per leaf.  Builds in milliseconds where the
+ * host SAH build takes seconds, for a tree that costs more node visits per ray;
+ * meant for scenes that change.  rtgpu_get_flat_scene returns a host copy
+ * (build_ms = GPU time of the build).  CPU restatement: oracle rto_build_lbvh. */
+int  rtgpu_upload_scene_lbvh(rtgpu_ctx *ctx, const rtgpu_scene_desc *scene);
 int  rtgpu_get_flat_scene(const rtgpu_ctx *ctx, rtgpu_flat_scene *out);
 
 /* Host-only variant of the two calls above: build + flatten without a GPU

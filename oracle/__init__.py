@@ -58,6 +58,9 @@ def load():
     lib.rto_resolve_rgba8.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     lib.rto_resolve_rgba8.restype = None
     lib.rto_validate_bvh.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+    lib.rto_build_lbvh.argtypes = [C.c_void_p, C.c_void_p]
+    lib.rto_flat_free.argtypes = [C.c_void_p]
+    lib.rto_flat_free.restype = None
     lib.rto_has_openmp.restype = C.c_int
     lib.rto_debug_max_stack.argtypes = [C.c_int]
     lib.rto_debug_max_stack.restype = C.c_int
@@ -118,6 +121,18 @@ class Oracle:
         out = np.zeros(accum.shape[:-1], np.uint32)
         self.lib.rto_resolve_rgba8(accum.ctypes.data, out.ctypes.data, accum.size // 4)
         return out
+
+    def build_lbvh(self, scene_desc, flat_struct_type):
+        """CPU restatement of the GPU LBVH builder: scene descriptor -> flattened scene
+        (a ctypes struct of the caller's rtgpu_flat_scene type; free with free_flat)."""
+        fs = flat_struct_type()
+        rc = self.lib.rto_build_lbvh(C.addressof(scene_desc), C.addressof(fs))
+        if rc:
+            raise RuntimeError(f"rto_build_lbvh failed with {rc}")
+        return fs
+
+    def free_flat(self, fs):
+        self.lib.rto_flat_free(C.addressof(fs))
 
     def validate_bvh(self, flat_c):
         d = C.c_uint32()

@@ -695,3 +695,260 @@ RTO_API int rto_has_openmp(void) {
   return 0;
 #endif
 }
+
+/* ==== LBVH builder restatement ================================
+ *
+ * CPU restatement of the GPU builder in rt_amd/csrc/lbvh_build.hip (no reference
+ * counterpart: the reference has no BVH).  Published algorithm:
+ * T. Karras, "Maximizing Parallelism in the Construction of BVHs, Octrees, and
+ * k-d Trees", HPG 2012 - Morton codes of the primitive centroids, one radix
+ * sort, the hierarchy from the longest common prefixes of neighbouring keys.
+ * Everything below is integer arithmetic or exact float min/max except the
+ * quantisation (c - cmin) * (1024 / ext), which both sides compute as separately
+ * rounded IEEE f32 operations.  The output is a flattened scene in the format of
+ * include/rtgpu_format.h, byte for byte what the GPU builder produces:
+ *
+ *  - prims: spheres first (index = sphere index), then triangles; key =
+ *    morton30(centroid) << 32 | index, sorted ascending (keys are unique);
+ *  - one primitive per leaf, leaf arrays in sorted order per type;
+ *  - internal node i of Karras' numbering (root = 0) covers a key range and splits
+ *    it where the common prefix changes; its record holds both children's boxes
+ *    (primitive boxes padded as the SAH builder pads them);
+ *  - renumbering: nodes whose subtree holds >= T = max(1, ceil(2P/4096))
+ *    primitives ("the top of the tree", fewer than 4096 of them) come first, in
+ *    Karras order, the others follow in Karras order (root stays 0).
+ */
+static inline uint32_t expand10(uint32_t v) { /* 10 bits -> every third bit */
+  v = (v | (v << 16)) & 0x030000FFu;
+  v = (v | (v << 8)) & 0x0300F00Fu;
+  v = (v | (v << 4)) & 0x030C30C3u;
+  v = (v | (v << 2)) & 0x09249249u;
+  return v;
+}
+
+static inline int clz64(uint64_t x) { return x ? __builtin_clzll(x) : 64; }
+
+static int cmp_u64(const void *a, const void *b) {
+  uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b;
+  return x < y ? -1 : x > y;
+}
+
+typedef struct { float lo[3], hi[3]; } box_t;
+
+static void prim_box(const rtgpu_scene_desc *sc, uint32_t i, box_t *b, float *cent) {
+  if (i < sc->n_spheres) {
+    const rtgpu_sphere *s = &sc->spheres[i];
+    for (int k = 0; k < 3; k++) {
+      b->lo[k] = s->center[k] - s->radius;
+      b->hi[k] = s->center[k] + s->radius;
+      cent[k] = s->center[k];
+    }
+  } else {
+    const rtgpu_triangle *t = &sc->triangles[i - sc->n_spheres];
+    for (int k = 0; k < 3; k++) {
+      b->lo[k] = fminf(t->v0[k], fminf(t->v1[k], t->v2[k]));
+      b->hi[k] = fmaxf(t->v0[k], fmaxf(t->v1[k], t->v2[k]));
+      cent[k] = (b->lo[k] + b->hi[k]) * 0.5f;
+    }
+  }
+}
+
+static void pad_box(box_t *b) { /* as rt_amd/csrc/bvh_build.cpp pad_box */
+  for (int k = 0; k < 3; k++) {
+    float m = fmaxf(fmaxf(fabsf(b->lo[k]), fabsf(b->hi[k])), 1.0f);
+    float e = m * (1.0f / 262144.0f);
+    b->lo[k] -= e;
+    b->hi[k] += e;
+  }
+}
+
+static inline int lbvh_delta(const uint64_t *keys, int64_t n, int64_t a, int64_t b) {
+  if (b < 0 || b >= n) return -1;
+  return clz64(keys[a] ^ keys[b]);
+}
+
+RTO_API void rto_flat_free(rtgpu_flat_scene *fs) {
+  if (!fs) return;
+  free((void *)fs->nodes); free((void *)fs->tris); free((void *)fs->spheres);
+  free((void *)fs->sphere_meta); free((void *)fs->materials);
+  memset(fs, 0, sizeof(*fs));
+}
+
+RTO_API int rto_build_lbvh(const rtgpu_scene_desc *sc, rtgpu_flat_scene *out) {
+  memset(out, 0, sizeof(*out));
+  const int64_t ns = (int64_t)sc->n_spheres, nt = (int64_t)sc->n_triangles, P = ns + nt;
+  const int64_t n_inner = P > 1 ? P - 1 : 1;
+  rtgpu_node *nodes = calloc((size_t)n_inner, sizeof(rtgpu_node));
+  rtgpu_tri *tris = calloc((size_t)nt + 8, sizeof(rtgpu_tri));
+  rtgpu_sph *sphs = calloc((size_t)ns + 8, sizeof(rtgpu_sph));
+  uint32_t *meta = calloc((size_t)(2 * ns + 16), sizeof(uint32_t));
+  rtgpu_material *mats = calloc(sc->n_materials ? sc->n_materials : 1, sizeof(rtgpu_material));
+  uint64_t *keys = malloc(sizeof(uint64_t) * (size_t)(P ? P : 1));
+  box_t *pbox = malloc(sizeof(box_t) * (size_t)(P ? P : 1));
+  if (!nodes || !tris || !sphs || !meta || !mats || !keys || !pbox) return 2;
+
+  /* materials: the flattener's dielectric constants (bvh_build.cpp) */
+  for (uint64_t k = 0; k < sc->n_materials; k++) {
+    mats[k] = sc->materials[k];
+    mats[k]._pad[0] = mats[k]._pad[1] = mats[k]._pad[2] = 0;
+    if (mats[k].type == RTGPU_MAT_DIELECTRIC) {
+      float ior = mats[k].param, inv = 1.0f / ior;
+      float qf = (1.0f - inv) / (1.0f + inv), qb = (1.0f - ior) / (1.0f + ior);
+      float v[3] = {inv, qf * qf, qb * qb};
+      memcpy(mats[k]._pad, v, sizeof(v));
+    }
+  }
+
+  /* boxes, centroid bounds, keys */
+  float cmin[3] = {INFINITY, INFINITY, INFINITY}, cmax[3] = {-INFINITY, -INFINITY, -INFINITY};
+  float *cent = malloc(sizeof(float) * 3 * (size_t)(P ? P : 1));
+  for (int64_t i = 0; i < P; i++) {
+    prim_box(sc, (uint32_t)i, &pbox[i], &cent[3 * i]);
+    pad_box(&pbox[i]);
+    for (int k = 0; k < 3; k++) {
+      cmin[k] = fminf(cmin[k], cent[3 * i + k]);
+      cmax[k] = fmaxf(cmax[k], cent[3 * i + k]);
+    }
+  }
+  float scale[3];
+  for (int k = 0; k < 3; k++) {
+    float ext = cmax[k] - cmin[k];
+    scale[k] = ext > 0.0f ? 1024.0f / ext : 0.0f;
+  }
+  for (int64_t i = 0; i < P; i++) {
+    uint32_t q[3];
+    for (int k = 0; k < 3; k++) {
+      float f = (cent[3 * i + k] - cmin[k]) * scale[k];
+      int v = (int)f;
+      q[k] = (uint32_t)(v < 0 ? 0 : v > 1023 ? 1023 : v);
+    }
+    uint32_t code = (expand10(q[0]) << 2) | (expand10(q[1]) << 1) | expand10(q[2]);
+    keys[i] = ((uint64_t)code << 32) | (uint64_t)i;
+  }
+  free(cent);
+  qsort(keys, (size_t)P, sizeof(uint64_t), cmp_u64);
+
+  /* leaf arrays in sorted order, and each sorted position's leaf reference */
+  uint32_t *leaf_ref = malloc(sizeof(uint32_t) * (size_t)(P ? P : 1));
+  uint32_t n_s = 0, n_t = 0;
+  for (int64_t k = 0; k < P; k++) {
+    uint32_t p = (uint32_t)keys[k];
+    if (p < (uint32_t)ns) {
+      const rtgpu_sphere *s = &sc->spheres[p];
+      sphs[n_s].c[0] = s->center[0]; sphs[n_s].c[1] = s->center[1]; sphs[n_s].c[2] = s->center[2];
+      sphs[n_s].r = s->radius;
+      meta[2 * n_s] = p; meta[2 * n_s + 1] = s->material;
+      leaf_ref[k] = RTGPU_REF_LEAF | RTGPU_REF_SPHERE | n_s;
+      n_s++;
+    } else {
+      const rtgpu_triangle *t = &sc->triangles[p - ns];
+      for (int c = 0; c < 3; c++) {
+        tris[n_t].v0[c] = t->v0[c];
+        tris[n_t].e1[c] = t->v1[c] - t->v0[c];
+        tris[n_t].e2[c] = t->v2[c] - t->v0[c];
+      }
+      tris[n_t].prim_id = p; tris[n_t].material = t->material; tris[n_t]._pad = 0;
+      leaf_ref[k] = RTGPU_REF_LEAF | n_t;
+      n_t++;
+    }
+  }
+
+  uint32_t max_depth = 0;
+  if (P <= 1) {
+    for (int k = 0; k < 3; k++) {
+      nodes[0].lo0[k] = nodes[0].lo1[k] = INFINITY;
+      nodes[0].hi0[k] = nodes[0].hi1[k] = INFINITY;
+    }
+    nodes[0].child0 = nodes[0].child1 = RTGPU_REF_EMPTY;
+    if (P == 1) {
+      for (int k = 0; k < 3; k++) { nodes[0].lo0[k] = pbox[0].lo[k]; nodes[0].hi0[k] = pbox[0].hi[k]; }
+      nodes[0].child0 = leaf_ref[0];
+      max_depth = 1;
+    }
+  } else {
+    /* Karras: range and split of every internal node; child code: >= 0 internal index, < 0 = ~leaf position */
+    int64_t *c0 = malloc(sizeof(int64_t) * (size_t)n_inner), *c1 = malloc(sizeof(int64_t) * (size_t)n_inner);
+    for (int64_t i = 0; i < n_inner; i++) {
+      int d = lbvh_delta(keys, P, i, i + 1) > lbvh_delta(keys, P, i, i - 1) ? 1 : -1;
+      int dmin = lbvh_delta(keys, P, i, i - d);
+      int64_t lmax = 2;
+      while (lbvh_delta(keys, P, i, i + lmax * d) > dmin) lmax *= 2;
+      int64_t l = 0;
+      for (int64_t t = lmax / 2; t >= 1; t /= 2)
+        if (lbvh_delta(keys, P, i, i + (l + t) * d) > dmin) l += t;
+      int64_t j = i + l * d;
+      int dnode = lbvh_delta(keys, P, i, j);
+      int64_t s = 0;
+      for (int64_t t = (l + 1) / 2;; t = (t + 1) / 2) {
+        if (lbvh_delta(keys, P, i, i + (s + t) * d) > dnode) s += t;
+        if (t == 1) break;
+      }
+      int64_t gamma = i + s * d + (d < 0 ? -1 : 0);
+      int64_t lo = i < j ? i : j, hi = i < j ? j : i;
+      c0[i] = gamma == lo ? ~gamma : gamma;
+      c1[i] = gamma + 1 == hi ? ~(gamma + 1) : gamma + 1;
+    }
+    /* boxes, sizes, heights bottom-up (a child always has ... no index order: iterate until done) */
+    box_t *nbox = malloc(sizeof(box_t) * (size_t)n_inner);
+    uint32_t *size = calloc((size_t)n_inner, sizeof(uint32_t)), *height = calloc((size_t)n_inner, sizeof(uint32_t));
+    uint8_t *done = calloc((size_t)n_inner, 1);
+    /* explicit stack post-order from the root */
+    int64_t *stk = malloc(sizeof(int64_t) * 256);
+    int sp = 0;
+    stk[sp++] = 0;
+    while (sp > 0) {
+      int64_t i = stk[sp - 1];
+      int64_t a = c0[i], b = c1[i];
+      int ready = (a < 0 || done[a]) && (b < 0 || done[b]);
+      if (!ready) {
+        if (a >= 0 && !done[a]) stk[sp++] = a;
+        if (b >= 0 && !done[b]) stk[sp++] = b;
+        if (sp > 250) return 3;
+        continue;
+      }
+      sp--;
+      const box_t *ba = a < 0 ? &pbox[(uint32_t)keys[~a]] : &nbox[a];
+      const box_t *bb = b < 0 ? &pbox[(uint32_t)keys[~b]] : &nbox[b];
+      for (int k = 0; k < 3; k++) {
+        nbox[i].lo[k] = fminf(ba->lo[k], bb->lo[k]);
+        nbox[i].hi[k] = fmaxf(ba->hi[k], bb->hi[k]);
+      }
+      uint32_t sa = a < 0 ? 1 : size[a], sb = b < 0 ? 1 : size[b];
+      uint32_t ha = a < 0 ? 0 : height[a], hb = b < 0 ? 0 : height[b];
+      size[i] = sa + sb;
+      height[i] = 1 + (ha > hb ? ha : hb);
+      done[i] = 1;
+    }
+    max_depth = height[0];
+    /* renumber: top nodes (subtree >= T prims) first, both groups in Karras order */
+    uint32_t T = (uint32_t)((2 * P + 4095) / 4096);
+    if (T < 1) T = 1;
+    uint32_t *new_of = malloc(sizeof(uint32_t) * (size_t)n_inner);
+    uint32_t n_top = 0;
+    for (int64_t i = 0; i < n_inner; i++) n_top += size[i] >= T;
+    uint32_t at_top = 0, at_rest = n_top;
+    for (int64_t i = 0; i < n_inner; i++) new_of[i] = size[i] >= T ? at_top++ : at_rest++;
+    for (int64_t i = 0; i < n_inner; i++) {
+      rtgpu_node *nd = &nodes[new_of[i]];
+      int64_t a = c0[i], b = c1[i];
+      const box_t *ba = a < 0 ? &pbox[(uint32_t)keys[~a]] : &nbox[a];
+      const box_t *bb = b < 0 ? &pbox[(uint32_t)keys[~b]] : &nbox[b];
+      for (int k = 0; k < 3; k++) {
+        nd->lo0[k] = ba->lo[k]; nd->hi0[k] = ba->hi[k];
+        nd->lo1[k] = bb->lo[k]; nd->hi1[k] = bb->hi[k];
+      }
+      nd->child0 = a < 0 ? leaf_ref[~a] : new_of[a];
+      nd->child1 = b < 0 ? leaf_ref[~b] : new_of[b];
+      nd->_pad[0] = nd->_pad[1] = 0;
+    }
+    free(c0); free(c1); free(nbox); free(size); free(height); free(done); free(stk); free(new_of);
+  }
+  free(keys); free(pbox); free(leaf_ref);
+  out->nodes = nodes; out->n_nodes = (uint64_t)n_inner;
+  out->tris = tris; out->n_tris = (uint64_t)nt;
+  out->spheres = sphs; out->n_spheres = (uint64_t)ns;
+  out->sphere_meta = meta;
+  out->materials = mats; out->n_materials = sc->n_materials;
+  out->max_depth = max_depth;
+  return 0;
+}

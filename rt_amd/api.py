@@ -150,6 +150,7 @@ lib.rtgpu_camera_look_at.restype = None
 lib.rtgpu_default_settings.argtypes = [_P(Settings), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
 lib.rtgpu_default_settings.restype = None
 lib.rtgpu_scene_builtin.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, _P(SceneDesc), _P(Camera), C.c_float]
+lib.rtgpu_upload_scene_lbvh.argtypes = [C.c_void_p, _P(SceneDesc)]
 lib.rtgpu_scene_free.argtypes = [_P(SceneDesc)]
 lib.rtgpu_scene_free.restype = None
 lib.rtgpu_scene_parse_obj.argtypes = [C.c_char_p, C.c_uint64, _P(SceneDesc)]
@@ -322,8 +323,14 @@ class Context:
         except Exception:
             pass
 
-    def upload(self, scene):
-        self._check(lib.rtgpu_upload_scene(self._h, C.byref(scene.desc)))
+    def upload(self, scene, builder="sah"):
+        """builder: "sah" = binned-SAH BVH on the host (default), "lbvh" = LBVH on the GPU."""
+        if builder == "lbvh":
+            self._check(lib.rtgpu_upload_scene_lbvh(self._h, C.byref(scene.desc)))
+        elif builder == "sah":
+            self._check(lib.rtgpu_upload_scene(self._h, C.byref(scene.desc)))
+        else:
+            raise ValueError(f"unknown builder {builder!r}")
 
     def flat_scene(self):
         fs = FlatSceneC()

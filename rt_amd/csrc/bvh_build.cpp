@@ -360,6 +360,61 @@ T *copy_out(const std::vector<T> &v, size_t min_elems = 1) {
 
 }  // namespace
 
+int validate_scene(const rtgpu_scene_desc *scene, std::string &err) {
+  if (!scene) { err = "scene is NULL"; return 1; }
+  if ((scene->n_spheres && !scene->spheres) || (scene->n_triangles && !scene->triangles) ||
+      (scene->n_materials && !scene->materials)) {
+    err = "scene array pointer is NULL with a non-zero count";
+    return 1;
+  }
+  if (scene->n_spheres > RTGPU_MAX_PRIMS_PER_TYPE || scene->n_triangles > RTGPU_MAX_PRIMS_PER_TYPE) {
+    err = "too many primitives (limit 134,217,720 per type)";
+    return 1;
+  }
+  if (scene->n_materials == 0 && (scene->n_spheres || scene->n_triangles)) {
+    err = "scene has primitives but no materials";
+    return 1;
+  }
+  for (uint64_t i = 0; i < scene->n_spheres; i++) {
+    const rtgpu_sphere &s = scene->spheres[i];
+    if (s.material >= scene->n_materials) { err = "sphere material index out of range"; return 1; }
+    if (!(s.radius > 0.f) || !std::isfinite(s.radius) || !std::isfinite(s.center[0]) ||
+        !std::isfinite(s.center[1]) || !std::isfinite(s.center[2])) {
+      err = "sphere with non-finite centre or non-positive radius";
+      return 1;
+    }
+  }
+  for (uint64_t i = 0; i < scene->n_triangles; i++) {
+    const rtgpu_triangle &t = scene->triangles[i];
+    if (t.material >= scene->n_materials) { err = "triangle material index out of range"; return 1; }
+    for (int k = 0; k < 3; k++)
+      if (!std::isfinite(t.v0[k]) || !std::isfinite(t.v1[k]) || !std::isfinite(t.v2[k])) {
+        err = "triangle with a non-finite vertex";
+        return 1;
+      }
+  }
+  return 0;
+}
+
+// Flattened materials keep the caller's 32 bytes and use the three pad words of
+// a dielectric for values the scatter step would otherwise divide for at every
+// hit: 1/ior, and Schlick's r0 = ((1 - ri) / (1 + ri))^2 for ri = 1/ior (front
+// face) and ri = ior (back face) - the same IEEE f32 operations, done once.
+rtgpu_material *flatten_materials(const rtgpu_scene_desc *scene) {
+  std::vector<rtgpu_material> mats(scene->materials, scene->materials + scene->n_materials);
+  for (rtgpu_material &m : mats) {
+    m._pad[0] = m._pad[1] = m._pad[2] = 0u;
+    if (m.type != RTGPU_MAT_DIELECTRIC) continue;
+    volatile float ior = m.param;  // volatile: keep each operation a separate rounded f32 op
+    volatile float inv = 1.0f / ior;
+    volatile float qf = (1.0f - inv) / (1.0f + inv);
+    volatile float qb = (1.0f - ior) / (1.0f + ior);
+    float v[3] = {inv, qf * qf, qb * qb};
+    std::memcpy(m._pad, v, sizeof(v));
+  }
+  return copy_out(mats);
+}
+
 int flatten_scene(const rtgpu_scene_desc *scene, rtgpu_flat_scene *out, std::string &err) {
   std::memset(out, 0, sizeof(*out));
   read_sah_env();
@@ -500,21 +555,6 @@ int flatten_scene(const rtgpu_scene_desc *scene, rtgpu_flat_scene *out, std::str
     return 1;
   }
 
-  // Flattened materials keep the caller's 32 bytes and use the three pad words of
-  // a dielectric for values the scatter step would otherwise divide for at every
-  // hit: 1/ior, and Schlick's r0 = ((1 - ri) / (1 + ri))^2 for ri = 1/ior (front
-  // face) and ri = ior (back face) - the same IEEE f32 operations, done once.
-  std::vector<rtgpu_material> mats(scene->materials, scene->materials + scene->n_materials);
-  for (rtgpu_material &m : mats) {
-    m._pad[0] = m._pad[1] = m._pad[2] = 0u;
-    if (m.type != RTGPU_MAT_DIELECTRIC) continue;
-    volatile float ior = m.param;  // volatile: keep each operation a separate rounded f32 op
-    volatile float inv = 1.0f / ior;
-    volatile float qf = (1.0f - inv) / (1.0f + inv);
-    volatile float qb = (1.0f - ior) / (1.0f + ior);
-    float v[3] = {inv, qf * qf, qb * qb};
-    std::memcpy(m._pad, v, sizeof(v));
-  }
   // +8 zeroed records behind the leaf-ordered arrays: a leaf reference can
   // name at most 8 primitives, so even a corrupt count cannot read past them.
   out->nodes       = copy_out(nodes);
@@ -524,8 +564,8 @@ int flatten_scene(const rtgpu_scene_desc *scene, rtgpu_flat_scene *out, std::str
   out->spheres     = copy_out(B.sphs, B.sphs.size() + 8);
   out->n_spheres   = B.sphs.size();
   out->sphere_meta = copy_out(B.sph_meta, B.sph_meta.size() + 16);
-  out->materials   = copy_out(mats);
-  out->n_materials = mats.size();
+  out->materials   = flatten_materials(scene);
+  out->n_materials = scene->n_materials;
   out->max_depth   = top.max_depth;
   if (!out->nodes || !out->tris || !out->spheres || !out->sphere_meta || !out->materials) {
     free_flat_scene(out);

@@ -12,6 +12,20 @@ namespace rtgpu {
 // bvh_build.cpp
 int  flatten_scene(const rtgpu_scene_desc *scene, rtgpu_flat_scene *out, std::string &err);
 void free_flat_scene(rtgpu_flat_scene *fs);
+// input checks of flatten_scene (NULL arrays, counts, material indices, finite geometry)
+int  validate_scene(const rtgpu_scene_desc *scene, std::string &err);
+// the caller's materials + the precomputed dielectric constants; malloc'ed, 64-byte aligned
+rtgpu_material *flatten_materials(const rtgpu_scene_desc *scene);
+
+// lbvh_build.hip: the same flattened scene built on the GPU (device arrays, caller frees with free_lbvh)
+struct LbvhDevice {
+  void *d_nodes, *d_tris, *d_sphs, *d_sph_meta;
+  uint64_t n_nodes;
+  uint32_t max_depth;
+  double gpu_ms;  // first kernel to last, HIP events
+};
+int  lbvh_build_device(const rtgpu_scene_desc *scene, LbvhDevice *out, std::string &err);
+void free_lbvh(LbvhDevice *out);
 
 // host_util.cpp
 void set_global_error(const std::string &msg);

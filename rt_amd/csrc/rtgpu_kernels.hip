@@ -1012,6 +1012,49 @@ extern "C" int rtgpu_upload_scene(rtgpu_ctx *ctx, const rtgpu_scene_desc *scene)
   return 0;
 }
 
+// As rtgpu_upload_scene, with the BVH built on the GPU (lbvh_build.hip).  The
+// flattened scene is also copied back to the host so that rtgpu_get_flat_scene
+// (and with it the oracle) sees exactly what the kernels traverse.
+extern "C" int rtgpu_upload_scene_lbvh(rtgpu_ctx *ctx, const rtgpu_scene_desc *scene) {
+  if (!ctx) return 1;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  free_scene_device(ctx);
+  if (rtgpu::validate_scene(scene, ctx->err)) return 1;
+  rtgpu::LbvhDevice L;
+  int rc = rtgpu::lbvh_build_device(scene, &L, ctx->err);
+  if (rc) return rc;
+  ctx->d_nodes = L.d_nodes; ctx->d_tris = L.d_tris; ctx->d_sphs = L.d_sphs; ctx->d_sph_meta = L.d_sph_meta;
+  rtgpu_flat_scene &h = ctx->host;
+  std::memset(&h, 0, sizeof(h));
+  h.n_nodes = L.n_nodes; h.n_tris = scene->n_triangles; h.n_spheres = scene->n_spheres;
+  h.n_materials = scene->n_materials; h.max_depth = L.max_depth; h.build_ms = L.gpu_ms;
+  const size_t nb = (size_t)h.n_nodes * sizeof(rtgpu_node), tb = ((size_t)h.n_tris + 8) * sizeof(rtgpu_tri),
+               sb = ((size_t)h.n_spheres + 8) * sizeof(rtgpu_sph), mb = ((size_t)h.n_spheres * 2 + 16) * sizeof(uint32_t);
+  void *hn = std::aligned_alloc(64, (nb + 63) / 64 * 64), *ht = std::aligned_alloc(64, (tb + 63) / 64 * 64),
+       *hs = std::aligned_alloc(64, (sb + 63) / 64 * 64), *hm = std::aligned_alloc(64, (mb + 63) / 64 * 64);
+  h.nodes = hn; h.tris = ht; h.spheres = hs; h.sphere_meta = (const uint32_t *)hm;
+  h.materials = rtgpu::flatten_materials(scene);
+  hipError_t e = hipSuccess;
+  if (!hn || !ht || !hs || !hm || !h.materials) {
+    ctx->err = "out of host memory for the flattened scene";
+    free_scene_device(ctx);
+    return 2;
+  }
+  if ((e = hipMemcpy(hn, ctx->d_nodes, nb, hipMemcpyDeviceToHost)) != hipSuccess ||
+      (e = hipMemcpy(ht, ctx->d_tris, tb, hipMemcpyDeviceToHost)) != hipSuccess ||
+      (e = hipMemcpy(hs, ctx->d_sphs, sb, hipMemcpyDeviceToHost)) != hipSuccess ||
+      (e = hipMemcpy(hm, ctx->d_sph_meta, mb, hipMemcpyDeviceToHost)) != hipSuccess ||
+      upload(ctx, &ctx->d_mats, h.materials, h.n_materials * sizeof(rtgpu_material))) {
+    std::string keep = e != hipSuccess ? std::string("lbvh: copy back: ") + hipGetErrorString(e) : ctx->err;
+    free_scene_device(ctx);
+    ctx->err = keep;
+    return 2;
+  }
+  ctx->have_scene = true;
+  return 0;
+}
+
 extern "C" int rtgpu_get_flat_scene(const rtgpu_ctx *ctx, rtgpu_flat_scene *out) {
   if (!ctx || !out || !ctx->have_scene) return 1;
   *out = ctx->host;

@@ -19,17 +19,20 @@ CONFIGS = {
 }
 
 def main():
-    names = [a for a in sys.argv[1:] if not a.startswith("--")] or ["c2", "c3", "c5"]
     reps = 5
-    if "--reps" in sys.argv:
-        reps = int(sys.argv[sys.argv.index("--reps") + 1])
+    args = sys.argv[1:]
+    if "--reps" in args:
+        k = args.index("--reps")
+        reps = int(args[k + 1])
+        del args[k:k + 2]
+    names = [a for a in args if not a.startswith("--")] or ["c2", "c3", "c5"]
     ctx = ra.Context(0)
     for name in names:
         kind, level, w, h, spp, depth = CONFIGS[name]
         t0 = time.time()
         scene, cam = ra.Scene.builtin(kind, param=level, aspect=w / h)
         t1 = time.time()
-        ctx.upload(scene)
+        ctx.upload(scene, builder=os.environ.get("RT_BUILDER", "sah"))
         t2 = time.time()
         fs = ctx.flat_scene()
         acc = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
@@ -47,7 +50,7 @@ def main():
         ms = np.array(ms)
         abytes = 64 * s["nodes"] + 48 * s["tri_tests"] + 16 * s["sphere_tests"] + 32 * s["scatters"] + 16 * w * h
         print(f"{name}: prims={scene.n_prims} nodes={fs.c.n_nodes} depth={fs.c.max_depth} gen={t1-t0:.1f}s "
-              f"build+upload={t2-t1:.1f}s (bvh {fs.c.build_ms/1e3:.1f}s) | {w}x{h}x{spp} rays={s['rays']} "
+              f"build+upload={t2-t1:.1f}s (bvh {fs.c.build_ms:.1f} ms) | {w}x{h}x{spp} rays={s['rays']} "
               f"nodes/ray={s['nodes']/s['rays']:.1f} tris/ray={s['tri_tests']/s['rays']:.1f} "
               f"sph/ray={s['sphere_tests']/s['rays']:.1f} B/ray={abytes/s['rays']:.0f} | "
               f"kernel ms min={ms.min():.3f} med={np.median(ms):.3f} -> {s['rays']/np.median(ms)/1e3:.0f} Mrays/s, "
