@@ -168,7 +168,7 @@ int  rtgpu_upload_scene(rtgpu_ctx *ctx, const rtgpu_scene_desc *scene);
  * flattened format, one primitive per leaf.  Builds in milliseconds where the
  * host SAH build takes seconds, for a tree that costs more node visits per ray;
  * meant for scenes that change.  rtgpu_get_flat_scene returns a host copy
- * (build_ms = GPU time of the build).  CPU restatement: oracle rto_build_lbvh. */
+ * (build_ms = GPU time of the build). */
 int  rtgpu_upload_scene_lbvh(rtgpu_ctx *ctx, const rtgpu_scene_desc *scene);
 int  rtgpu_get_flat_scene(const rtgpu_ctx *ctx, rtgpu_flat_scene *out);
 

@@ -17,7 +17,7 @@
 // primitive per leaf, nodes with large subtrees numbered first so the kernel's
 // LDS node cache holds the top of the tree.
 //
-// The CPU restatement is oracle/rt_oracle.c rto_build_lbvh; tests compare the two
+// The CPU restatement lives under oracle/ (test infrastructure); tests compare the two
 // byte for byte.  Everything is integer arithmetic or exact float min/max except
 // the quantisation (c - cmin) * (1024 / ext): separately rounded IEEE f32
 // operations on both sides (this file is compiled with -ffp-contract=off).
