@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak (spec)
 VALU_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 vector (spec)
+VALU_ISSUE_PEAK_GINST = 614.4  # 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction
 
 
 def algorithmic_bytes(st, n_pixels):
@@ -51,11 +52,11 @@ def measured_traffic(width, height, spp, depth, world):
     try:
         doc = json.load(open(path))
     except (OSError, ValueError):
-        return None, None
+        return None, None, None
     wl = doc.get("workload", {})
     if world != 1 or [wl.get(k) for k in ("width", "height", "spp", "depth")] != [width, height, spp, depth]:
-        return None, None
-    return int(doc["traffic_bytes_per_launch"]), doc.get("source")
+        return None, None, None
+    return int(doc["traffic_bytes_per_launch"]), doc.get("source"), doc
 
 
 def cpu_baseline(width, height, depth, sample_spp):
@@ -201,7 +202,7 @@ def main():
         abytes = algorithmic_bytes(counts, n_px_rank)
         aflops = algorithmic_flops(counts)
         achieved = abytes / (k_ms * 1e-3) / 1e9
-        traffic, traffic_src = measured_traffic(W, H, args.spp, depth, world)
+        traffic, traffic_src, pmc = measured_traffic(W, H, args.spp, depth, world)
         out = {
             "metric": "Mrays/s (whole job)", "value": round(rays_per_step * args.steps / dt / 1e6, 2),
             "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -232,6 +233,15 @@ def main():
                          "frac": round(aflops / (k_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4),
                          "flops_per_ray": round(aflops / counts["rays"], 1)},
                 "kernel_mrays_per_s": round(counts["rays"] / (k_ms * 1e-3) / 1e6, 1),
+                # the bound that actually holds on this workload: VALU issue slots.  A wave64 VALU
+                # instruction occupies its SIMD for 4 cycles: 1024 SIMDs x 2.4 GHz / 4 = 614.4 G
+                # wave-instructions/s.  Instruction count from the committed PMC pass of this workload.
+                "valu_issue": None if not pmc or "valu_insts_per_launch" not in pmc else {
+                    "achieved_ginst_per_s": round(pmc["valu_insts_per_launch"] / (k_ms * 1e-3) / 1e9, 1),
+                    "peak_ginst_per_s": VALU_ISSUE_PEAK_GINST,
+                    "frac": round(pmc["valu_insts_per_launch"] / (k_ms * 1e-3) / 1e9 / VALU_ISSUE_PEAK_GINST, 3),
+                    "lane_utilisation": pmc.get("valu_lane_utilisation"),
+                    "insts_per_ray": round(pmc["valu_insts_per_launch"] * 64 / counts["rays"], 1)},
             },
         }
         if args.cpu_spp > 0 and world == 1:
