@@ -6,7 +6,8 @@ import os
 
 import numpy as np
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "librtgpu.so")
+# RTGPU_LIB: an experimental build of the same library (developer knob, see tools/)
+LIB_PATH = os.environ.get("RTGPU_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "librtgpu.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

@@ -31,12 +31,24 @@
 
 namespace {
 
-constexpr int      kBlock      = 1024; // one block per CU: 16 waves share one LDS copy of the top of the BVH
+// Launch shape: kBlocksPerCU blocks of kBlock threads per CU, each with an equal share of
+// the CU's LDS.  (Macros so that tools/ can build variants for occupancy experiments.)
+#ifndef RTGPU_KBLOCK
+#define RTGPU_KBLOCK 1024
+#endif
+#ifndef RTGPU_BLOCKS_PER_CU
+#define RTGPU_BLOCKS_PER_CU 1
+#endif
+#ifndef RTGPU_WAVES_PER_EU
+#define RTGPU_WAVES_PER_EU (RTGPU_KBLOCK * RTGPU_BLOCKS_PER_CU / 256)
+#endif
+constexpr int      kBlock      = RTGPU_KBLOCK;
+constexpr int      kBlocksPerCU = RTGPU_BLOCKS_PER_CU; // one block per CU: 16 waves share one LDS copy of the top of the BVH
 constexpr int      kStackLds   = 32;   // most entries per lane the LDS stack may get (4 KiB per entry per block)
-constexpr int      kLdsBytes   = 160 * 1024;  // LDS per CU on gfx950; one block takes all of it
+constexpr int      kLdsBytes   = 160 * 1024 / kBlocksPerCU - (kBlocksPerCU > 1 ? 2048 : 0);  // LDS per CU on gfx950, shared equally by the CU's blocks
 constexpr int      kStackOvf   = RTGPU_MAX_TREE_DEPTH + 2;  // global overflow entries per lane (covers stack_lds >= 2)
 constexpr uint32_t kDone       = 0xFFFFFFFFu;  // == RTGPU_REF_EMPTY, has the leaf bit
-constexpr int      kSmallNodes = 1024; // MODE 2 of the trace kernel: whole tree in LDS, planes 16 KiB apart
+constexpr int      kSmallNodes = kBlocksPerCU == 1 ? 1024 : 512;  // MODE 2 of the trace kernel: whole tree in LDS, planes this many nodes apart
 constexpr unsigned kChunk      = 64;   // work items drawn per queue atomic (one 8x8 pixel block)
 constexpr float    kTMax       = 3.402823466e+38f;  // FLT_MAX: initial closest-hit distance
 
@@ -230,7 +242,8 @@ __device__ __forceinline__ void wave_tick(unsigned lane, unsigned long long &c) 
 // four planes a compile-time distance apart, so a node fetch is one address and four
 // ds_read with immediate offsets, and no "cached or not" test.
 template <int STATS, int REFILL, int MODE>
-__global__ __launch_bounds__(kBlock) void trace_kernel(const KParams P) {
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RTGPU_WAVES_PER_EU, RTGPU_WAVES_PER_EU)))
+void trace_kernel(const KParams P) {
   constexpr bool LDS_ONLY = MODE >= 1, SMALL = MODE == 2;
   // LDS: [traversal stacks: stack_lds x kBlock u32][node cache: 4 planes x n_cached float4]
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -958,9 +971,9 @@ extern "C" int rtgpu_create(rtgpu_ctx **out, int device_index) {
           rtgpu_destroy(ctx);
           return 2;
         }
-  ctx->blocks_per_cu[0] = ctx->blocks_per_cu[1] = 1;
-  ctx->ovf_threads = (size_t)ctx->num_cus * kBlock;
-  if ((e = hipMalloc((void **)&ctx->d_wave_times, (size_t)ctx->num_cus * (kBlock / 64) * 3 * 8)) != hipSuccess) {
+  ctx->blocks_per_cu[0] = ctx->blocks_per_cu[1] = kBlocksPerCU;
+  ctx->ovf_threads = (size_t)ctx->num_cus * kBlocksPerCU * kBlock;
+  if ((e = hipMalloc((void **)&ctx->d_wave_times, (size_t)ctx->num_cus * kBlocksPerCU * (kBlock / 64) * 3 * 8)) != hipSuccess) {
     rtgpu::set_global_error(std::string("rtgpu_create: ") + hipGetErrorString(e));
     rtgpu_destroy(ctx);
     return 2;
@@ -1129,6 +1142,8 @@ extern "C" int rtgpu_render_device(rtgpu_ctx *ctx, const rtgpu_camera *cam, cons
   uint32_t need = ctx->host.max_depth + 2u;
   uint32_t stack_lds = need < 8u ? 8u : need;
   if (stack_lds > (uint32_t)ctx->stack_lds) stack_lds = (uint32_t)ctx->stack_lds;  // kStackLds, or RTGPU_STACK_LDS
+  const uint32_t stack_fit = (uint32_t)(kLdsBytes / (kBlock * sizeof(uint32_t)));      // entries the block's LDS share holds
+  if (stack_lds > stack_fit) stack_lds = stack_fit;
   P.stack_lds = stack_lds;
   P.stack_lds_only = need <= stack_lds ? 1u : 0u;
   size_t lds_left = (size_t)kLdsBytes - (size_t)stack_lds * kBlock * sizeof(uint32_t);
@@ -1190,11 +1205,21 @@ extern "C" int rtgpu_profile_counters(rtgpu_ctx *ctx, uint64_t out[32]) {
   return 0;
 }
 
+// Diagnostics (not in the public header): blocks of the production variant (MODE 1) the
+// runtime says fit on one CU with `lds_bytes` of dynamic LDS each.
+extern "C" int rtgpu_debug_occupancy(rtgpu_ctx *ctx, uint64_t lds_bytes, int *blocks_per_cu) {
+  if (!ctx || !blocks_per_cu) return 1;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, (const void *)kVariants[ctx->variant].fn[0][1],
+                                                            kBlock, (size_t)lds_bytes));
+  return 0;
+}
+
 // Diagnostics (not in the public header): {start, end, queue-dry} 100 MHz
 // timestamps of every wave of the last RTGPU_FLAG_PROFILE launch.
 extern "C" int rtgpu_debug_wave_times(rtgpu_ctx *ctx, uint64_t *out, uint64_t max_waves, uint64_t *n_waves) {
   if (!ctx || !out || !n_waves) return 1;
-  uint64_t n = (uint64_t)ctx->num_cus * (kBlock / 64);
+  uint64_t n = (uint64_t)ctx->num_cus * kBlocksPerCU * (kBlock / 64);
   if (n > max_waves) n = max_waves;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipDeviceSynchronize());
