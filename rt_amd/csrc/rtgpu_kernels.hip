@@ -11,14 +11,15 @@
 // rt::Vec3 (code/math/vec.cxx:94-97 dot = mul then x+y+z; :66-69 normalize =
 // v * (1/len); :174-211 component-wise operators).
 //
-// Structure: persistent threads.  Each lane owns one pixel at a time and
-// walks its samples in order (the frame sum is formed sequentially per pixel,
-// which keeps accumulation deterministic); a lane whose pixel is finished
-// draws the next one from a global queue with one atomic per wave
-// (ballot + mbcnt prefix), so waves stay full until the queue is dry.
-// Traversal is a while-while loop over the 64-byte BVH2 nodes with a per-lane
-// short stack in LDS ([entry][thread], conflict-free) that overflows into
-// scratch for the rare deep path.
+// Structure: persistent threads, one 1024-thread block per CU that
+// owns the CU's LDS: per-lane traversal stacks ([entry][thread], conflict-free)
+// and a copy of the top of the BVH in four 16-byte planes.  A lane owns one work
+// item = (pixel, chunk of samples) at a time and walks its samples in order; work
+// items come from a global queue in groups of 64 (one atomic per group), chunk
+// sums go to per-chunk planes and combine_kernel adds them in order, which keeps
+// the frame sum deterministic.  Traversal runs in voted phases (node steps /
+// one-primitive leaf steps) and is left early when few lanes still traverse, so
+// finished lanes shade and start their next ray.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>

@@ -217,6 +217,17 @@ def test_chunked_frame_sum(ra, oracle, gpu_ctx, spp, chunk):
     assert_bit_equal(a2, b2, "accumulate")
 
 
+def test_default_chunk_rule_at_high_spp(ra, oracle, gpu_ctx):
+    """Beyond 128 spp rtgpu_default_settings grows the chunks (at most 64 planes)."""
+    scene, cam = ra.Scene.builtin(0, aspect=96 / 54)
+    st = ra.default_settings(96, 54, spp=200, max_depth=8)
+    assert st.chunk_samples == 4
+    (a, ia, sa), (b, ib, sb) = render_both(ra, oracle, gpu_ctx, scene, cam, st)
+    assert np.array_equal(ia, ib)
+    assert_bit_equal(a, b, "200 spp, default chunks")
+    assert sa == sb
+
+
 def test_progressive_accumulation(ra, oracle, gpu_ctx):
     scene, cam = ra.Scene.builtin(0, aspect=160 / 90)
     gpu_ctx.upload(scene)
