@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -137,7 +138,14 @@ struct Builder {
     if (T <= 1) { fn(b, e, 0); return; }
     std::vector<std::thread> th;
     size_t n = e - b;
-    for (int t = 1; t < T; t++) th.emplace_back(fn, b + n * (size_t)t / (size_t)T, b + n * (size_t)(t + 1) / (size_t)T, t);
+    for (int t = 1; t < T; t++) {
+      size_t cb = b + n * (size_t)t / (size_t)T, ce = b + n * (size_t)(t + 1) / (size_t)T;
+      try {
+        th.emplace_back(fn, cb, ce, t);
+      } catch (const std::system_error &) {  // no thread to be had: this chunk runs here
+        fn(cb, ce, t);
+      }
+    }
     fn(b, b + n / (size_t)T, 0);
     for (auto &x : th) x.join();
   }
@@ -320,9 +328,14 @@ struct Builder {
     R.sph_at = S.sph_at + left_sph;  R.tri_at = S.tri_at + ((mid - b) - left_sph);
     Box b0, b1;
     uint32_t c0 = 0, c1 = 0;
-    std::thread left([&] { c0 = build_tasks(L, b, mid, depth + 1, b0); });
+    std::thread left;
+    try {
+      left = std::thread([&] { c0 = build_tasks(L, b, mid, depth + 1, b0); });
+    } catch (const std::system_error &) {  // no thread to be had: build the left subtree here
+      c0 = build_tasks(L, b, mid, depth + 1, b0);
+    }
     c1 = build_tasks(R, mid, e, depth + 1, b1);
-    left.join();
+    if (left.joinable()) left.join();
     S.sph_at = R.sph_at;
     S.tri_at = R.tri_at;
     S.max_depth = std::max(S.max_depth, std::max(L.max_depth, R.max_depth));
