@@ -179,8 +179,16 @@ struct Stack {
   uint32_t *ovf;        // &ovf[global thread]
   uint32_t ovf_stride;  // threads in the grid
   int lds_entries;      // entries of the LDS part in use (<= kStackLds)
-  int sp;               // next free entry; >= 1 while a traversal is running
-  __device__ __forceinline__ void reset() { sp = 1; }
+  int sp;               // next free entry; >= 1 while a traversal is running (overflow-capable form)
+  // LDS_ONLY form: the stack pointer IS the LDS address of the top entry (32-bit, explicit
+  // address space), so a step needs no index -> address arithmetic
+  typedef __attribute__((address_space(3))) uint32_t lds_u32;
+  lds_u32 *top_at;      // &entry[sp - 1] of this lane
+  lds_u32 *base_at;     // &entry[0] of this lane (the sentinel)
+  __device__ __forceinline__ void reset() {
+    sp = 1;
+    top_at = base_at;
+  }
   __device__ __forceinline__ void store(int at, uint32_t v) {
     if (LDS_ONLY || at < lds_entries) lds[at * kBlock] = v;
     else ovf[(size_t)(at - lds_entries) * ovf_stride] = v;
@@ -192,10 +200,9 @@ struct Stack {
   // node step: push `far_c` if both children were hit, pop if none was
   __device__ __forceinline__ uint32_t step(bool both, bool none, uint32_t near_c, uint32_t far_c) {
     if (LDS_ONLY) {
-      uint32_t *below = lds_m1 + sp * kBlock;  // one address: top at [0], free entry at [kBlock] (immediate offset)
-      uint32_t top = below[0];
-      below[kBlock] = far_c;
-      sp += (both ? 1 : 0) - (none ? 1 : 0);
+      uint32_t top = top_at[0];   // one address: top at [0], free entry at [kBlock] (immediate offset)
+      top_at[kBlock] = far_c;
+      top_at += both ? kBlock : (none ? -kBlock : 0);
       return none ? top : near_c;
     }
     if (both) { store(sp, far_c); sp++; }
@@ -205,8 +212,8 @@ struct Stack {
   // leaf step: pop if the leaf is exhausted
   __device__ __forceinline__ uint32_t pop_if(bool doit) {
     if (LDS_ONLY) {
-      uint32_t top = lds_m1[sp * kBlock];
-      sp -= doit ? 1 : 0;
+      uint32_t top = top_at[0];
+      top_at -= doit ? kBlock : 0;
       return top;
     }
     uint32_t v = kDone;
@@ -277,8 +284,10 @@ void trace_kernel(const KParams P) {
   V3 inv = mk(1.f, 1.f, 1.f), noi = mk(0.f, 0.f, 0.f);
   f2 inv_xy = mk2(1.f, 1.f), inv_zx = inv_xy, inv_yz = inv_xy, noi_xy = mk2(0.f, 0.f), noi_zx = noi_xy, noi_yz = noi_xy;
   float tbest = kTMax;
-  uint32_t hit_slot = 0, cur = kDone;
-  int hit_kind = 0;  // 0 none, 1 sphere, 2 triangle
+  uint32_t cur = kDone;
+  // closest hit so far: the leaf cursor at the time of the hit (type bit + slot of the
+  // primitive in its leaf-ordered array), kDone = none
+  uint32_t hit_ref = kDone;
   unsigned pool_next = 0, pool_end = 0;  // wave-local slice of the work queue (wave-uniform)
   // wave-uniform description of the group the pool was drawn from (see (2))
   uint32_t g_px = 0, g_py = 0, g_out = 0, g_row = 0, g_chunk = 0, g_sample = 0, g_sample_end = 0;
@@ -286,6 +295,8 @@ void trace_kernel(const KParams P) {
   Stack<LDS_ONLY> stk;
   stk.lds = lds_stack + tid;
   stk.lds_m1 = lds_stack + tid - kBlock;  // never dereferenced below sp = 1
+  stk.base_at = (typename Stack<LDS_ONLY>::lds_u32 *)(lds_stack + tid);
+  stk.top_at = stk.base_at;
   stk.ovf_stride = gridDim.x * kBlock;
   stk.ovf = P.ovf_stack + (size_t)blockIdx.x * kBlock + tid;
   stk.sp = 1;
@@ -324,7 +335,8 @@ void trace_kernel(const KParams P) {
       if (STATS == 2) { wave_tick(lane, w_shade); l_shade++; }
       V3 L = mk(0.f, 0.f, 0.f);
       bool path_end = false;
-      if (hit_kind == 0) {
+      const uint32_t hit_slot = RTGPU_REF_FIRST(hit_ref);
+      if (hit_ref == kDone) {
         float t = 0.5f * (rd.y + 1.0f);
         float a = 1.0f - t;
         V3 sky = mk(P.sky_bottom[0] * a + P.sky_top[0] * t, P.sky_bottom[1] * a + P.sky_top[1] * t,
@@ -335,7 +347,7 @@ void trace_kernel(const KParams P) {
         V3 p = ro + rd * tbest;
         V3 n;
         uint32_t prim, mat;
-        if (hit_kind == 1) {
+        if (hit_ref & RTGPU_REF_SPHERE) {
           float4 s = P.sphs[hit_slot];
           uint2 meta = P.sph_meta[hit_slot];
           float inv_r = 1.0f / s.w;
@@ -573,7 +585,7 @@ void trace_kernel(const KParams P) {
       inv_xy = mk2(inv.x, inv.y); inv_zx = mk2(inv.z, inv.x); inv_yz = mk2(inv.y, inv.z);
       noi_xy = mk2(noi.x, noi.y); noi_zx = mk2(noi.z, noi.x); noi_yz = mk2(noi.y, noi.z);
       tbest = kTMax;
-      hit_kind = 0;
+      hit_ref = kDone;
       cur = 0;  // root
       stk.reset();
       n_rays++;
@@ -670,10 +682,10 @@ void trace_kernel(const KParams P) {
             float t2 = -hb + sq;
             bool ok2 = t2 > tmin && t2 < tbest;
             t = ok ? t : t2;
-            if (ok || ok2) { tbest = t; hit_slot = i; hit_kind = 1; }
+            if (ok || ok2) { tbest = t; hit_ref = cur; }
           }
           if (at_tri) {
-            const float4 *tp = (const float4 *)(tris_base + i * 48u);  // 32-bit offset: < 4 GiB of triangles
+            const float4 *tp = (const float4 *)(tris_base + ((i << 5) + (i << 4)));  // i * 48 as shifts (v_mul_lo_u32 is quarter rate); 32-bit offset: < 4 GiB of triangles
             float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
             if (STATS) n_tris++;
             if (STATS == 2) wave_tick(lane, w_tri);
@@ -689,7 +701,7 @@ void trace_kernel(const KParams P) {
             float v = dot(rd, qvec) * inv_det;
             valid = valid && !(v < 0.0f || u + v > 1.0f);
             float t = dot(e2, qvec) * inv_det;
-            if (valid && t > tmin && t < tbest) { tbest = t; hit_slot = i; hit_kind = 2; }
+            if (valid && t > tmin && t < tbest) { tbest = t; hit_ref = cur; }
           }
           if (at_leaf) {
             uint32_t next = cur + 1u - (1u << 27);  // first+1, count-1
