@@ -49,7 +49,9 @@ constexpr int      kStackLds   = 32;   // most entries per lane the LDS stack ma
 constexpr int      kLdsBytes   = 160 * 1024 / kBlocksPerCU - (kBlocksPerCU > 1 ? 2048 : 0);  // LDS per CU on gfx950, shared equally by the CU's blocks
 constexpr int      kStackOvf   = RTGPU_MAX_TREE_DEPTH + 2;  // global overflow entries per lane (covers stack_lds >= 2)
 constexpr uint32_t kDone       = 0xFFFFFFFFu;  // == RTGPU_REF_EMPTY, has the leaf bit
-constexpr int      kSmallNodes = kBlocksPerCU == 1 ? 1024 : 512;  // MODE 2 of the trace kernel: whole tree in LDS, planes this many nodes apart
+// MODE 2 of the trace kernel: whole tree in LDS, planes this many nodes apart (the last
+// plane's immediate ds_read offset, 3 * 16 * kSmallNodes, has to fit in 16 bits)
+constexpr int      kSmallNodes = kBlocksPerCU == 1 ? 1365 : 512;
 constexpr unsigned kChunk      = 64;   // work items drawn per queue atomic (one 8x8 pixel block)
 constexpr float    kTMax       = 3.402823466e+38f;  // FLT_MAX: initial closest-hit distance
 
@@ -307,8 +309,8 @@ void trace_kernel(const KParams P) {
   // quarter j of DIFFERENT nodes, and in this layout consecutive nodes sit in
   // consecutive 16-byte bank groups (measured 56 cycles per 64-lane node fetch
   // vs 142 for node-major LDS and 181 through the vector L1, tools/ubench).
-  const uint32_t n_cached = P.n_cached;
-  const uint32_t plane = SMALL ? (uint32_t)kSmallNodes : n_cached;  // nodes per plane
+  const uint32_t n_cached = SMALL ? P.n_cached : 0u;
+  const uint32_t plane = (uint32_t)kSmallNodes;  // nodes per plane
   for (uint32_t i = tid; i < n_cached * 4u; i += kBlock) {
     float4 v = P.nodes[i];
     f4 w = {v.x, v.y, v.z, v.w};
@@ -616,7 +618,10 @@ void trace_kernel(const KParams P) {
           if ((int)cur >= 0) {
             if (STATS == 2) wave_tick(lane, w_node);
             float4 q0, q1, q2, q3;
-            if (SMALL || cur < n_cached) {
+            // MODE 0/1 (tree larger than the LDS cache) fetch every node through L1: a
+            // partial cache measured no gain on the big scenes and costs a
+            // test and two branches per step
+            if (SMALL) {
               f4 w0 = node_cache[cur], w1 = node_cache[plane + cur], w2 = node_cache[2u * plane + cur],
                  w3 = node_cache[3u * plane + cur];
               q0 = make_float4(w0.x, w0.y, w0.z, w0.w);
@@ -1151,7 +1156,7 @@ extern "C" int rtgpu_render_device(rtgpu_ctx *ctx, const rtgpu_camera *cam, cons
   P.inv_tiles_x = 1.0f / (float)g.tiles_x;
   // LDS budget of the one block per CU: the stack gets what the tree depth
   // needs (pushes never exceed the depth; +1 sentinel, +1 for the unconditional
-  // store above the top), the node cache gets the rest.
+  // store above the top).
   uint32_t need = ctx->host.max_depth + 2u;
   uint32_t stack_lds = need < 8u ? 8u : need;
   if (stack_lds > (uint32_t)ctx->stack_lds) stack_lds = (uint32_t)ctx->stack_lds;  // kStackLds, or RTGPU_STACK_LDS
@@ -1159,19 +1164,17 @@ extern "C" int rtgpu_render_device(rtgpu_ctx *ctx, const rtgpu_camera *cam, cons
   if (stack_lds > stack_fit) stack_lds = stack_fit;
   P.stack_lds = stack_lds;
   P.stack_lds_only = need <= stack_lds ? 1u : 0u;
-  size_t lds_left = (size_t)kLdsBytes - (size_t)stack_lds * kBlock * sizeof(uint32_t);
-  uint64_t fit = lds_left / sizeof(rtgpu_node);
-  uint64_t top = ctx->host.n_nodes < RTGPU_TOP_NODES ? ctx->host.n_nodes : RTGPU_TOP_NODES;
-  P.n_cached = (uint32_t)(fit < top ? fit : top);
-  if (ctx->no_node_cache) P.n_cached = 0;
-  size_t lds_bytes = (size_t)stack_lds * kBlock * sizeof(uint32_t) + (size_t)P.n_cached * sizeof(rtgpu_node);
-  // small scenes: the whole tree in LDS with planes kSmallNodes apart (MODE 2)
+  // small scenes: the whole tree in LDS with planes kSmallNodes apart (MODE 2); larger
+  // trees are fetched through L1 (a partial cache measured no gain)
+  const size_t stack_bytes = (size_t)stack_lds * kBlock * sizeof(uint32_t);
+  size_t lds_bytes = stack_bytes;
   int mode = P.stack_lds_only ? 1 : 0;
+  P.n_cached = 0;
   if (mode == 1 && !ctx->no_node_cache && ctx->host.n_nodes <= (uint64_t)kSmallNodes &&
-      P.n_cached == ctx->host.n_nodes &&
-      (size_t)stack_lds * kBlock * sizeof(uint32_t) + (size_t)kSmallNodes * sizeof(rtgpu_node) <= (size_t)kLdsBytes) {
+      stack_bytes + (size_t)kSmallNodes * sizeof(rtgpu_node) <= (size_t)kLdsBytes) {
     mode = 2;
-    lds_bytes = (size_t)stack_lds * kBlock * sizeof(uint32_t) + (size_t)kSmallNodes * sizeof(rtgpu_node);
+    P.n_cached = (uint32_t)ctx->host.n_nodes;
+    lds_bytes = stack_bytes + (size_t)kSmallNodes * sizeof(rtgpu_node);
   }
 
   bool want_stats = (s->flags & (RTGPU_FLAG_STATS | RTGPU_FLAG_PROFILE)) != 0;
