@@ -154,6 +154,52 @@ def test_edge_cases(ra, oracle, gpu_ctx):
             assert sa == sb, name
 
 
+def _random_scene(ra, rng, n_sph, n_tri):
+    mats = [(int(rng.integers(0, 3)), *rng.uniform(0.2, 1.0, 3).tolist(),
+             float(rng.choice([0.0, 0.2, 1.0, 1.5]))) for _ in range(6)]
+    mats = [(t, r, g, b, (1.5 if p == 0.0 else p) if t == 2 else (0.0 if t == 0 else min(p, 1.0)))
+            for (t, r, g, b, p) in mats]
+    sph = [(*rng.uniform(-3, 3, 3).tolist(), float(rng.uniform(0.05, 0.8)), int(rng.integers(0, 6)))
+           for _ in range(n_sph)]
+    tri = []
+    for _ in range(n_tri):
+        c = rng.uniform(-3, 3, 3)
+        tri.append((tuple(c + rng.normal(0, .5, 3)), tuple(c + rng.normal(0, .5, 3)),
+                    tuple(c + rng.normal(0, .5, 3)), int(rng.integers(0, 6))))
+    return make_scene(ra, spheres=sph, triangles=tri, materials=mats)
+
+
+@pytest.mark.parametrize("seed,n_sph,n_tri", [(1, 40, 0), (2, 0, 60), (3, 150, 150), (4, 700, 900), (5, 3, 2),
+                                              (6, 1200, 1200)])
+def test_random_scenes(ra, oracle, gpu_ctx, seed, n_sph, n_tri):
+    """Seeded random soups of overlapping spheres and triangles with random materials,
+    seen from inside: every kernel mode (whole tree in LDS up to 1365 nodes, larger trees
+    through L1), both primitive types in one tree, rays starting inside glass."""
+    rng = np.random.default_rng(seed)
+    scene = _random_scene(ra, rng, n_sph, n_tri)
+    cam = ra.look_at(tuple(rng.uniform(-1, 1, 3)), tuple(rng.uniform(-3, 3, 3)), vfov=70.0, aspect=96 / 64)
+    st = ra.default_settings(96, 64, spp=3, max_depth=6, seed=seed, flags=ra.FLAG_STATS)
+    (a, ia, sa), (b, ib, sb) = render_both(ra, oracle, gpu_ctx, scene, cam, st)
+    assert np.array_equal(ia, ib)
+    assert_bit_equal(a, b, f"random scene {seed}")
+    assert sa == sb and sa["rays"] >= 96 * 64 * 3
+
+
+def test_scene_replacement(ra, oracle, gpu_ctx):
+    """A context renders whatever was uploaded last; going back gives the first frame again."""
+    s0, cam0 = ra.Scene.builtin(0, aspect=2.0)
+    s1, cam1 = ra.Scene.builtin(1, param=4, aspect=2.0)
+    st = ra.default_settings(128, 64, spp=2, max_depth=6)
+    gpu_ctx.upload(s0)
+    a0, i0, _ = gpu_ctx.render(cam0, st)
+    gpu_ctx.upload(s1)
+    a1, i1, _ = gpu_ctx.render(cam1, st)
+    gpu_ctx.upload(s0)
+    a2, i2, _ = gpu_ctx.render(cam0, st)
+    assert_bit_equal(a0, a2, "first scene again")
+    assert np.array_equal(i0, i2) and not np.array_equal(i0, i1)
+
+
 def test_deep_tree_and_stack_overflow(ra, oracle, gpu_ctx):
     """A chain of spheres gives a BVH ~30 deep and traversal stacks of > 20
     entries.  Default context: the whole stack lives in LDS (32 entries).  A
