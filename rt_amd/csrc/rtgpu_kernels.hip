@@ -98,7 +98,41 @@ __device__ __forceinline__ float dot(V3 a, V3 b) { a = a * b; return a.x + a.y +
 __device__ __forceinline__ V3 cross(V3 a, V3 b) {
   return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
-__device__ __forceinline__ V3 normalize(V3 a) { return a * (1.0f / __builtin_sqrtf(dot(a, a))); }
+// 1/x and sqrt(x) with the BITS of IEEE division and sqrtf (what the oracle computes)
+// in a third of the instructions hipcc emits for them.  hipcc's sequences rescale
+// tiny/huge operands and fix up special values; on the ranges below none of that is
+// needed, which tools/ubench/exact_rcp_sqrt.hip verifies EXHAUSTIVELY on gfx950 (all
+// 2^32 inputs against hipcc's own sequences):
+//   rcp_fast (v_rcp_f32 + one Newton step in fma form) == 1.0f / x  for 2^-126 <= |x| < 2^126
+//   sqrt_fast (v_sqrt_f32, then s-1ulp / s / s+1ulp chosen by exact fma residuals)
+//             == sqrtf(x)  for x == 0, x >= 2^-104, inf and NaN (x < 0: NaN either way)
+// rcp_exact / sqrt_exact take any operand: if some lane of the wave is outside the
+// verified range the whole wave takes hipcc's sequence (a wave-uniform branch).
+__device__ __forceinline__ float rcp_fast(float x) {
+  float r = __builtin_amdgcn_rcpf(x);
+  float e = __builtin_fmaf(-x, r, 1.0f);
+  return __builtin_fmaf(e, r, r);
+}
+__device__ __forceinline__ float sqrt_fast(float x) {
+  float s = __builtin_amdgcn_sqrtf(x);
+  float sm = __uint_as_float(__float_as_uint(s) - 1u), sp = __uint_as_float(__float_as_uint(s) + 1u);
+  float rm = __builtin_fmaf(-sm, s, x), rp = __builtin_fmaf(-sp, s, x);
+  s = rm <= 0.0f ? sm : s;
+  s = rp > 0.0f ? sp : s;
+  return s;
+}
+__device__ __forceinline__ float rcp_exact(float x) {
+  const float a = __builtin_fabsf(x);
+  const bool in_range = a >= 0x1p-126f && a < 0x1p126f;  // false for NaN
+  if (__builtin_expect(__ballot(!in_range) == 0ull, 1)) return rcp_fast(x);
+  return 1.0f / x;
+}
+__device__ __forceinline__ float sqrt_exact(float x) {
+  const bool out_of_range = x > 0.0f && x < 0x1p-104f;
+  if (__builtin_expect(__ballot(out_of_range) == 0ull, 1)) return sqrt_fast(x);
+  return __builtin_sqrtf(x);
+}
+__device__ __forceinline__ V3 normalize(V3 a) { return a * rcp_exact(sqrt_exact(dot(a, a))); }
 __device__ __forceinline__ float fmin_(float a, float b) { return __builtin_fminf(a, b); }
 __device__ __forceinline__ float fmax_(float a, float b) { return __builtin_fmaxf(a, b); }
 // v_max_f32 / v_min_f32 as written (IEEE mode: same value as fmaxf/fminf for non-NaN
@@ -146,7 +180,7 @@ __device__ __forceinline__ V3 random_unit_vector(Rng &rng) {
     float ts = ta * ta + tb * tb;
     if (ts < 1.0f) { a = ta; b = tb; s = ts; found = true; }
   }
-  float f = 2.0f * __builtin_sqrtf(1.0f - s);
+  float f = 2.0f * sqrt_fast(1.0f - s);  // 1 - s is 1 or a multiple of 2^-24 in (0, 1)
   return mk(a * f, b * f, 1.0f - 2.0f * s);
 }
 
@@ -352,7 +386,7 @@ void trace_kernel(const KParams P) {
         if (hit_ref & RTGPU_REF_SPHERE) {
           float4 s = P.sphs[hit_slot];
           uint2 meta = P.sph_meta[hit_slot];
-          float inv_r = 1.0f / s.w;
+          float inv_r = rcp_exact(s.w);
           n = (p - mk(s.x, s.y, s.z)) * inv_r;
           prim = meta.x;
           mat = meta.y;
@@ -395,7 +429,7 @@ void trace_kernel(const KParams P) {
           // material (bvh_build.cpp): the same f32 operations, done once on the host
           float ri = front ? m1.y : param;
           float cos_t = fmin_(-dot(rd, n), 1.0f);
-          float sin_t = __builtin_sqrtf(1.0f - cos_t * cos_t);
+          float sin_t = sqrt_exact(1.0f - cos_t * cos_t);
           bool cannot = ri * sin_t > 1.0f;
           float r0 = front ? m1.z : m1.w;
           float xx = 1.0f - cos_t;
@@ -407,7 +441,7 @@ void trace_kernel(const KParams P) {
             sd = reflect(rd, n);
           } else {
             V3 perp = (rd + n * cos_t) * ri;
-            float par = -__builtin_sqrtf(__builtin_fabsf(1.0f - dot(perp, perp)));
+            float par = -sqrt_exact(__builtin_fabsf(1.0f - dot(perp, perp)));
             sd = perp + n * par;
           }
         }
@@ -582,7 +616,8 @@ void trace_kernel(const KParams P) {
     // ---- (3) start the traversal of every new segment --------------------------
     if (alive && cur == kDone) {
       rd = normalize(new_dir);
-      inv = mk(1.0f / clamp_dir(rd.x), 1.0f / clamp_dir(rd.y), 1.0f / clamp_dir(rd.z));
+      // |clamp_dir(d)| lies in [1e-30, 1] for every finite direction: inside rcp_fast's verified range
+      inv = mk(rcp_fast(clamp_dir(rd.x)), rcp_fast(clamp_dir(rd.y)), rcp_fast(clamp_dir(rd.z)));
       noi = mk(-(ro.x * inv.x), -(ro.y * inv.y), -(ro.z * inv.z));
       inv_xy = mk2(inv.x, inv.y); inv_zx = mk2(inv.z, inv.x); inv_yz = mk2(inv.y, inv.z);
       noi_xy = mk2(noi.x, noi.y); noi_zx = mk2(noi.z, noi.x); noi_yz = mk2(noi.y, noi.z);
@@ -681,7 +716,7 @@ void trace_kernel(const KParams P) {
             float hb = dot(oc, rd);
             float cc = dot(oc, oc) - s.w * s.w;
             float disc = hb * hb - cc;
-            float sq = __builtin_sqrtf(disc);  // NaN for a negative discriminant: fails every test below
+            float sq = sqrt_exact(disc);  // NaN for a negative discriminant: fails every test below
             float t = -hb - sq;
             bool ok = t > tmin && t < tbest;
             float t2 = -hb + sq;
@@ -698,7 +733,7 @@ void trace_kernel(const KParams P) {
             V3 pvec = cross(rd, e2);
             float det = dot(e1, pvec);
             bool valid = !(__builtin_fabsf(det) < 1e-30f);
-            float inv_det = 1.0f / det;
+            float inv_det = rcp_exact(det);
             V3 tvec = ro - v0;
             float u = dot(tvec, pvec) * inv_det;
             valid = valid && !(u < 0.0f || u > 1.0f);
