@@ -1256,6 +1256,43 @@ extern "C" int rtgpu_profile_counters(rtgpu_ctx *ctx, uint64_t out[32]) {
   return 0;
 }
 
+// Exhaustive self-check of rcp_fast / sqrt_fast / rcp_exact / sqrt_exact against hipcc's
+// IEEE sequences: every one of the 2^32 bit patterns.  out[0], out[1]: inputs INSIDE the
+// verified ranges on which rcp_fast / sqrt_fast differ; out[2], out[3]: inputs (any) on
+// which the guarded rcp_exact / sqrt_exact differ.  All four must be zero.
+__global__ __launch_bounds__(256) void check_exact_math_kernel(unsigned long long *out) {
+  const unsigned long long i0 = ((unsigned long long)blockIdx.x * 256ull + threadIdx.x) * 256ull;
+  unsigned long long bad[4] = {0, 0, 0, 0};
+  for (unsigned k = 0; k < 256; k++) {
+    const uint32_t bits = (uint32_t)(i0 + k);
+    const float x = __uint_as_float(bits), a = __builtin_fabsf(x);
+    auto differ = [](float p, float q) { return __float_as_uint(p) != __float_as_uint(q) && !(p != p && q != q); };
+    const float want_r = 1.0f / x;
+    if (a >= 0x1p-126f && a < 0x1p126f && differ(rcp_fast(x), want_r)) bad[0]++;
+    if (differ(rcp_exact(x), want_r)) bad[2]++;
+    if (!(bits & 0x80000000u) || x != x) {  // sqrt: non-negative operands and NaNs
+      const float want_s = __builtin_sqrtf(x);
+      if ((x == 0.0f || x >= 0x1p-104f || x != x) && differ(sqrt_fast(x), want_s)) bad[1]++;
+      if (differ(sqrt_exact(x), want_s)) bad[3]++;
+    }
+  }
+  for (int c = 0; c < 4; c++)
+    if (bad[c]) atomicAdd(&out[c], bad[c]);
+}
+
+// Diagnostics (not in the public header): see check_exact_math_kernel.
+extern "C" int rtgpu_debug_check_exact_math(rtgpu_ctx *ctx, uint64_t out[4]) {
+  if (!ctx || !out) return 1;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  HIP_TRY(ctx, hipMemset(ctx->d_counters, 0, 256));
+  hipLaunchKernelGGL(check_exact_math_kernel, dim3((1u << 24) / 256), dim3(256), 0, 0, ctx->d_counters);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  HIP_TRY(ctx, hipMemcpy(out, ctx->d_counters, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  return 0;
+}
+
 // Diagnostics (not in the public header): blocks of the production variant (MODE 1) the
 // runtime says fit on one CU with `lds_bytes` of dynamic LDS each.
 extern "C" int rtgpu_debug_occupancy(rtgpu_ctx *ctx, uint64_t lds_bytes, int *blocks_per_cu) {

@@ -39,6 +39,17 @@ def test_native_library_is_loaded(ra):
     assert "librtgpu.so" in maps and os.path.exists(ra.LIB_PATH)
 
 
+def test_exact_reciprocal_and_sqrt_all_inputs(ra, gpu_ctx):
+    """The kernel's short 1/x and sqrt sequences give the bits of IEEE division and sqrtf:
+    checked on the GPU for every one of the 2^32 float bit patterns (inside the verified
+    ranges for the bare sequences, everywhere for the guarded ones)."""
+    import ctypes as C
+    out = (C.c_uint64 * 4)()
+    ra.lib.rtgpu_debug_check_exact_math.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    assert ra.lib.rtgpu_debug_check_exact_math(gpu_ctx._h, out) == 0
+    assert list(out) == [0, 0, 0, 0], list(out)
+
+
 def test_golden_fixture_without_oracle(ra, gpu_ctx):
     """Committed vectors only (no oracle in the loop): S0 64x36, 1 and 4 spp."""
     scene, cam = ra.Scene.builtin(0, aspect=64 / 36)
