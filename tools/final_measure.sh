@@ -18,3 +18,9 @@ timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/cali
 tail -2 "$OUT/calib.log"
 bash tools/pmc_passes.sh c2 $TAG/pmc_c2 > "$OUT/pmc_c2.log" 2>&1
 tail -12 "$OUT/pmc_c2.log"
+bash tools/pmc_passes.sh c3 $TAG/pmc_c3 > "$OUT/pmc_c3.log" 2>&1
+tail -8 "$OUT/pmc_c3.log"
+timeout -k 10 200 python3 tools/gpu_perf.py c2 c3 c5 c5full > "$OUT/perf.log" 2>&1
+cat "$OUT/perf.log"
+timeout -k 10 200 python3 tools/gpu_divergence.py c2 c3 c5 > "$OUT/divergence.log" 2>&1
+cat "$OUT/divergence.log"
