@@ -215,6 +215,7 @@ def main():
                             + (", RCCL gather to rank 0" if compact and not share_gpu else "")
                             + (" [REHEARSAL: all ranks on one GPU, gloo gather via host]" if share_gpu else ""),
                 "rays_per_step": int(rays_per_step), "paths_per_step": W * H * spp,
+                "mrays_per_s_per_gpu": round(rays_per_step * args.steps / dt / 1e6 / world, 2),
                 "ms_per_frame_1080p_16spp": round(dt / args.steps * 1e3, 4) if world == 1 else None,
             },
             "roofline": {
