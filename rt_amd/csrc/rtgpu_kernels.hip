@@ -725,7 +725,11 @@ void trace_kernel(const KParams P) {
             if (ok || ok2) { tbest = t; hit_ref = cur; }
           }
           if (at_tri) {
-            const float4 *tp = (const float4 *)(tris_base + ((i << 5) + (i << 4)));  // i * 48 as shifts (v_mul_lo_u32 is quarter rate); 32-bit offset: < 4 GiB of triangles
+            // i * 48 as (i * 3) << 4 with the * 3 spelled as one v_lshl_add_u32: hipcc turns any
+            // C spelling back into v_mul_lo_u32, which is quarter rate.  32-bit offset: < 4 GiB of triangles
+            uint32_t i3;
+            asm("v_lshl_add_u32 %0, %1, 1, %1" : "=v"(i3) : "v"(i));
+            const float4 *tp = (const float4 *)(tris_base + (i3 << 4));
             float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
             if (STATS) n_tris++;
             if (STATS == 2) wave_tick(lane, w_tri);
