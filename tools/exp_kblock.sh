@@ -14,7 +14,7 @@ if [ "$1" = build ]; then
   for cfg in "$@"; do
     set -- $cfg
     ( cd rt_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -std=c++17 -O3 -fPIC -ffp-contract=off -fno-fast-math \
-        -I../../include -I. -DRTGPU_KBLOCK=$1 -DRTGPU_BLOCKS_PER_CU=$2 -DRTGPU_WAVES_PER_EU=$3 -c -o build/k_exp.o rtgpu_kernels.hip &&
+        -fno-slp-vectorize -I../../include -I. -DRTGPU_KBLOCK=$1 -DRTGPU_BLOCKS_PER_CU=$2 -DRTGPU_WAVES_PER_EU=$3 -c -o build/k_exp.o rtgpu_kernels.hip &&
       /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../librtgpu_x$1x$2w$3.so build/k_exp.o build/lbvh_build.o \
         build/bvh_build.o build/host_util.o build/scenes.o build/scene_io.o -lpthread )
     echo "built rt_amd/librtgpu_x$1x$2w$3.so"
