@@ -211,7 +211,6 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 template <bool LDS_ONLY>
 struct Stack {
   uint32_t *lds;        // &lds_stack[tid]
-  uint32_t *lds_m1;     // lds - kBlock: the entry below `sp` is lds_m1[sp * kBlock]
   uint32_t *ovf;        // &ovf[global thread]
   uint32_t ovf_stride;  // threads in the grid
   int lds_entries;      // entries of the LDS part in use (<= kStackLds)
@@ -330,7 +329,6 @@ void trace_kernel(const KParams P) {
   bool queue_dry = false;                // wave-uniform: the global head has passed n_items
   Stack<LDS_ONLY> stk;
   stk.lds = lds_stack + tid;
-  stk.lds_m1 = lds_stack + tid - kBlock;  // never dereferenced below sp = 1
   stk.base_at = (typename Stack<LDS_ONLY>::lds_u32 *)(lds_stack + tid);
   stk.top_at = stk.base_at;
   stk.ovf_stride = gridDim.x * kBlock;
