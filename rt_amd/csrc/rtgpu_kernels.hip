@@ -915,15 +915,19 @@ namespace {
 
 // Kernel variants: {refill threshold} x {plain, instrumented}.  One source, one
 // code path; the threshold only changes WHEN finished lanes are refilled, never
-// what a path computes.  RTGPU_REFILL (0/16) selects it for experiments.
+// what a path computes.  RTGPU_REFILL (0/16/32) selects it for experiments.
 using KernelFn = void (*)(const KParams);
 struct Variant { int refill; KernelFn fn[3][3]; };  // [plain, stats, profile][MODE 0, 1, 2 of trace_kernel]
 #define RTGPU_VARIANT(R)                                                                   \
   {R, {{trace_kernel<0, R, 0>, trace_kernel<0, R, 1>, trace_kernel<0, R, 2>},               \
        {trace_kernel<1, R, 0>, trace_kernel<1, R, 1>, trace_kernel<1, R, 2>},               \
        {trace_kernel<2, R, 0>, trace_kernel<2, R, 1>, trace_kernel<2, R, 2>}}}
-const Variant kVariants[] = {RTGPU_VARIANT(0), RTGPU_VARIANT(16)};
-constexpr int kDefaultVariant = 1;  // refill below 16 traversing lanes (measured best on C2/C3/C5)
+const Variant kVariants[] = {RTGPU_VARIANT(0), RTGPU_VARIANT(16), RTGPU_VARIANT(32)};
+// Default refill threshold, by what bounds the scene: 16 where the whole tree
+// sits in LDS and the kernel is VALU-bound (an outer iteration is expensive, so leave
+// the traversal loop late); 32 where nodes come through the texture path, whose cost is
+// per load INSTRUCTION however few lanes take part (so keep traversal steps full).
+constexpr int kVariantSmallTree = 1, kVariantLargeTree = 2;
 
 bool hip_fail(rtgpu_ctx *ctx, hipError_t e, const char *what) {
   if (e == hipSuccess) return false;
@@ -1005,7 +1009,7 @@ extern "C" int rtgpu_create(rtgpu_ctx **out, int device_index) {
     return 2;
   }
   ctx->num_cus = prop.multiProcessorCount;
-  ctx->variant = kDefaultVariant;
+  ctx->variant = -1;  // by scene, unless RTGPU_REFILL names one
   if (const char *env = std::getenv("RTGPU_REFILL")) {
     int want = std::atoi(env);
     for (int i = 0; i < (int)(sizeof(kVariants) / sizeof(kVariants[0])); i++)
@@ -1222,7 +1226,7 @@ extern "C" int rtgpu_render_device(rtgpu_ctx *ctx, const rtgpu_camera *cam, cons
     uint64_t cap = (uint64_t)ctx->num_cus * (uint64_t)ctx->blocks_per_cu[want_stats ? 1 : 0];
     unsigned grid = (unsigned)(want < cap ? want : cap);
     if ((size_t)grid * kBlock > ctx->ovf_threads) { ctx->err = "internal: grid exceeds the overflow stack"; return 2; }
-    const Variant &var = kVariants[ctx->variant];
+    const Variant &var = kVariants[ctx->variant >= 0 ? ctx->variant : (mode == 2 ? kVariantSmallTree : kVariantLargeTree)];
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
     KernelFn fn = var.fn[(s->flags & RTGPU_FLAG_PROFILE) ? 2 : want_stats ? 1 : 0][mode];
     hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), lds_bytes, stream, P);
@@ -1300,7 +1304,7 @@ extern "C" int rtgpu_debug_check_exact_math(rtgpu_ctx *ctx, uint64_t out[4]) {
 extern "C" int rtgpu_debug_occupancy(rtgpu_ctx *ctx, uint64_t lds_bytes, int *blocks_per_cu) {
   if (!ctx || !blocks_per_cu) return 1;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, (const void *)kVariants[ctx->variant].fn[0][1],
+  HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, (const void *)kVariants[ctx->variant >= 0 ? ctx->variant : kVariantLargeTree].fn[0][1],
                                                             kBlock, (size_t)lds_bytes));
   return 0;
 }
