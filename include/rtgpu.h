@@ -170,6 +170,16 @@ int  rtgpu_upload_scene(rtgpu_ctx *ctx, const rtgpu_scene_desc *scene);
  * meant for scenes that change.  rtgpu_get_flat_scene returns a host copy
  * (build_ms = GPU time of the build). */
 int  rtgpu_upload_scene_lbvh(rtgpu_ctx *ctx, const rtgpu_scene_desc *scene);
+/* New positions (and material table) under the UNCHANGED tree of the uploaded
+ * scene: `scene` must hold the same number of spheres, triangles and materials,
+ * primitive i being the moved / edited primitive i.  Leaf records and every box
+ * are recomputed on the GPU (rt_amd/csrc/refit.hip); topology, leaf order and
+ * primitive ids stay, so for unchanged positions the tree is byte-identical.  The
+ * tree's quality degrades as the geometry moves away from what it was built for:
+ * upload again when frames slow down.  No reference counterpart (the reference
+ * has no BVH; §8f row 3 names builder + refit).  On a device error
+ * the scene is dropped and must be uploaded again. */
+int  rtgpu_refit(rtgpu_ctx *ctx, const rtgpu_scene_desc *scene);
 int  rtgpu_get_flat_scene(const rtgpu_ctx *ctx, rtgpu_flat_scene *out);
 
 /* Host-only variant of the two calls above: build + flatten without a GPU

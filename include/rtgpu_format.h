@@ -27,7 +27,8 @@ typedef struct rtgpu_node {
  *   bit 31 = 1 : leaf; bit 30 = 1 sphere / 0 triangle;
  *                bits 27..29 = count-1 (1..8 primitives, one type per leaf);
  *                bits 0..26  = first index into the leaf-ordered array
- *   0xFFFFFFFF : empty child (only in scenes of < 2 primitives); its box sits
+ *   0xFFFFFFFF : empty child (only under the root of a scene whose primitives fit
+ *                one leaf: fewer than 2, or 2..4 of one type); its box sits
  *                at +inf on every axis and the closest-hit distance starts at
  *                FLT_MAX, so the slab test can never pass for it              */
 #define RTGPU_REF_LEAF    0x80000000u

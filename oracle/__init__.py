@@ -59,6 +59,7 @@ def load():
     lib.rto_resolve_rgba8.restype = None
     lib.rto_validate_bvh.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
     lib.rto_build_lbvh.argtypes = [C.c_void_p, C.c_void_p]
+    lib.rto_refit.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.rto_flat_free.argtypes = [C.c_void_p]
     lib.rto_flat_free.restype = None
     lib.rto_has_openmp.restype = C.c_int
@@ -129,6 +130,15 @@ class Oracle:
         rc = self.lib.rto_build_lbvh(C.addressof(scene_desc), C.addressof(fs))
         if rc:
             raise RuntimeError(f"rto_build_lbvh failed with {rc}")
+        return fs
+
+    def refit(self, flat_c, scene_desc):
+        """CPU restatement of the GPU refit: same topology, geometry and materials of
+        `scene_desc`.  Returns a new flattened scene (free with free_flat)."""
+        fs = type(flat_c)()
+        rc = self.lib.rto_refit(C.addressof(flat_c), C.addressof(scene_desc), C.addressof(fs))
+        if rc:
+            raise RuntimeError(f"rto_refit failed with {rc}")
         return fs
 
     def free_flat(self, fs):

@@ -952,3 +952,111 @@ RTO_API int rto_build_lbvh(const rtgpu_scene_desc *sc, rtgpu_flat_scene *out) {
   out->max_depth = max_depth;
   return 0;
 }
+
+/* ==== Refit restatement ("builder + refit") =====================
+ *
+ * CPU restatement of rt_amd/csrc/refit.hip (no reference counterpart: the
+ * reference has no BVH).  Keeps the TOPOLOGY of a flattened scene -
+ * child references, leaf order, primitive ids - and takes the geometry and
+ * material indices from `sc`, which must hold the same number of spheres,
+ * triangles and materials the tree was built from:
+ *   - every leaf-ordered primitive record is rewritten from the primitive its id
+ *     names (triangle edges = f32 differences, as the builders store them);
+ *   - the box a node stores for a leaf child = union of the padded boxes of the
+ *     leaf's primitives; for an inner child = union of the two boxes that child
+ *     stores.  min/max are exact, so any evaluation order gives the same bytes.
+ * Output: a new flattened scene (free with rto_flat_free). */
+static void refit_child(const rtgpu_flat_scene *fs, const rtgpu_scene_desc *sc, const rtgpu_node *nodes,
+                        const rtgpu_tri *tris, const uint32_t *meta, uint32_t ref, float *lo, float *hi) {
+  (void)fs;
+  if (ref == RTGPU_REF_EMPTY) { for (int k = 0; k < 3; k++) lo[k] = hi[k] = INFINITY; return; }
+  if (ref & RTGPU_REF_LEAF) {
+    uint32_t first = RTGPU_REF_FIRST(ref), count = RTGPU_REF_COUNT(ref);
+    for (int k = 0; k < 3; k++) { lo[k] = INFINITY; hi[k] = -INFINITY; }
+    for (uint32_t i = first; i < first + count; i++) {
+      uint32_t p = (ref & RTGPU_REF_SPHERE) ? meta[2 * (size_t)i] : tris[i].prim_id;
+      box_t b; float c[3];
+      prim_box(sc, p, &b, c);
+      pad_box(&b);
+      for (int k = 0; k < 3; k++) { lo[k] = fminf(lo[k], b.lo[k]); hi[k] = fmaxf(hi[k], b.hi[k]); }
+    }
+    return;
+  }
+  const rtgpu_node *n = &nodes[ref];
+  for (int k = 0; k < 3; k++) { lo[k] = fminf(n->lo0[k], n->lo1[k]); hi[k] = fmaxf(n->hi0[k], n->hi1[k]); }
+}
+
+RTO_API int rto_refit(const rtgpu_flat_scene *in, const rtgpu_scene_desc *sc, rtgpu_flat_scene *out) {
+  memset(out, 0, sizeof(*out));
+  if (in->n_spheres != sc->n_spheres || in->n_tris != sc->n_triangles || in->n_materials != sc->n_materials) return 1;
+  const size_t nn = (size_t)in->n_nodes, nt = (size_t)in->n_tris, ns = (size_t)in->n_spheres;
+  rtgpu_node *nodes = malloc((nn ? nn : 1) * sizeof(rtgpu_node));
+  rtgpu_tri *tris = calloc(nt + 8, sizeof(rtgpu_tri));
+  rtgpu_sph *sphs = calloc(ns + 8, sizeof(rtgpu_sph));
+  uint32_t *meta = calloc(2 * ns + 16, sizeof(uint32_t));
+  rtgpu_material *mats = calloc(sc->n_materials ? sc->n_materials : 1, sizeof(rtgpu_material));
+  uint8_t *done = calloc(nn ? nn : 1, 1);
+  uint32_t *stk = malloc(sizeof(uint32_t) * 2 * (RTGPU_MAX_TREE_DEPTH + 4));
+  if (!nodes || !tris || !sphs || !meta || !mats || !done || !stk) return 2;
+  memcpy(nodes, in->nodes, nn * sizeof(rtgpu_node));
+  memcpy(tris, in->tris, nt * sizeof(rtgpu_tri));
+  memcpy(meta, in->sphere_meta, 2 * ns * sizeof(uint32_t));
+  for (uint64_t k = 0; k < sc->n_materials; k++) {  /* as rto_build_lbvh */
+    mats[k] = sc->materials[k];
+    mats[k]._pad[0] = mats[k]._pad[1] = mats[k]._pad[2] = 0;
+    if (mats[k].type == RTGPU_MAT_DIELECTRIC) {
+      float ior = mats[k].param, inv = 1.0f / ior;
+      float qf = (1.0f - inv) / (1.0f + inv), qb = (1.0f - ior) / (1.0f + ior);
+      float v[3] = {inv, qf * qf, qb * qb};
+      memcpy(mats[k]._pad, v, sizeof(v));
+    }
+  }
+  for (size_t i = 0; i < nt; i++) {
+    uint32_t p = tris[i].prim_id;
+    if (p < ns || p - ns >= nt) return 3;
+    const rtgpu_triangle *t = &sc->triangles[p - ns];
+    for (int c = 0; c < 3; c++) {
+      tris[i].v0[c] = t->v0[c];
+      tris[i].e1[c] = t->v1[c] - t->v0[c];
+      tris[i].e2[c] = t->v2[c] - t->v0[c];
+    }
+    tris[i].material = t->material;
+  }
+  for (size_t i = 0; i < ns; i++) {
+    uint32_t p = meta[2 * i];
+    if (p >= ns) return 3;
+    const rtgpu_sphere *s = &sc->spheres[p];
+    sphs[i].c[0] = s->center[0]; sphs[i].c[1] = s->center[1]; sphs[i].c[2] = s->center[2];
+    sphs[i].r = s->radius;
+    meta[2 * i + 1] = s->material;
+  }
+  /* post-order from the root with an explicit stack */
+  int sp = 0;
+  if (nn) stk[sp++] = 0;
+  while (sp > 0) {
+    uint32_t i = stk[sp - 1];
+    rtgpu_node *n = &nodes[i];
+    uint32_t a = n->child0, b = n->child1;
+    int ia = !(a & RTGPU_REF_LEAF), ib = !(b & RTGPU_REF_LEAF);  /* EMPTY has the leaf bit */
+    if ((ia && a >= nn) || (ib && b >= nn)) return 3;
+    int ready = (!ia || done[a]) && (!ib || done[b]);
+    if (!ready) {
+      if (sp + 2 > (int)(2 * (RTGPU_MAX_TREE_DEPTH + 4))) return 3;
+      if (ia && !done[a]) stk[sp++] = a;
+      if (ib && !done[b]) stk[sp++] = b;
+      continue;
+    }
+    sp--;
+    refit_child(in, sc, nodes, tris, meta, a, n->lo0, n->hi0);
+    refit_child(in, sc, nodes, tris, meta, b, n->lo1, n->hi1);
+    done[i] = 1;
+  }
+  free(done); free(stk);
+  out->nodes = nodes; out->n_nodes = in->n_nodes;
+  out->tris = tris; out->n_tris = in->n_tris;
+  out->spheres = sphs; out->n_spheres = in->n_spheres;
+  out->sphere_meta = meta;
+  out->materials = mats; out->n_materials = sc->n_materials;
+  out->max_depth = in->max_depth;
+  return 0;
+}

@@ -152,6 +152,7 @@ lib.rtgpu_default_settings.argtypes = [_P(Settings), C.c_uint32, C.c_uint32, C.c
 lib.rtgpu_default_settings.restype = None
 lib.rtgpu_scene_builtin.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, _P(SceneDesc), _P(Camera), C.c_float]
 lib.rtgpu_upload_scene_lbvh.argtypes = [C.c_void_p, _P(SceneDesc)]
+lib.rtgpu_refit.argtypes = [C.c_void_p, _P(SceneDesc)]
 lib.rtgpu_scene_free.argtypes = [_P(SceneDesc)]
 lib.rtgpu_scene_free.restype = None
 lib.rtgpu_scene_parse_obj.argtypes = [C.c_char_p, C.c_uint64, _P(SceneDesc)]
@@ -332,6 +333,11 @@ class Context:
             self._check(lib.rtgpu_upload_scene(self._h, C.byref(scene.desc)))
         else:
             raise ValueError(f"unknown builder {builder!r}")
+
+    def refit(self, scene):
+        """New positions / materials under the uploaded tree (rtgpu_refit): `scene` must
+        hold the uploaded scene's counts, primitive i being the moved primitive i."""
+        self._check(lib.rtgpu_refit(self._h, C.byref(scene.desc)))
 
     def flat_scene(self):
         fs = FlatSceneC()

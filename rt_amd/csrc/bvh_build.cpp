@@ -519,7 +519,23 @@ int flatten_scene(const rtgpu_scene_desc *scene, rtgpu_flat_scene *out, std::str
   } else {
     Box bounds;
     uint32_t r = B.build_tasks(top, 0, n, 0, bounds);
-    if (r != 0) { err = "internal: root is not node 0"; return 1; }
+    if (r & RTGPU_REF_LEAF) {
+      // 2..4 primitives of one type that SAH keeps together: the traversal starts at
+      // a node, so the leaf hangs under a root with an empty sibling (as for n == 1)
+      rtgpu_node root;
+      std::memset(&root, 0, sizeof(root));
+      for (int k = 0; k < 3; k++) {
+        root.lo0[k] = bounds.lo[k];  root.hi0[k] = bounds.hi[k];
+        root.lo1[k] = inv_lo;        root.hi1[k] = inv_hi;
+      }
+      root.child0 = r;
+      root.child1 = RTGPU_REF_EMPTY;
+      top.nodes.push_back(root);
+      top.max_depth = 1;
+    } else if (r != 0) {
+      err = "internal: root is not node 0";
+      return 1;
+    }
   }
   if (top.tri_at != B.tris.size() || top.sph_at != B.sphs.size()) {
     err = "internal: leaf arrays not filled";

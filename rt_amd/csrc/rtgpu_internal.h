@@ -27,6 +27,10 @@ struct LbvhDevice {
 int  lbvh_build_device(const rtgpu_scene_desc *scene, LbvhDevice *out, std::string &err);
 void free_lbvh(LbvhDevice *out);
 
+// refit.hip: new geometry under the uploaded tree's topology, in place on the device arrays
+int  refit_device(const rtgpu_scene_desc *scene, void *d_nodes, uint64_t n_nodes, void *d_tris, void *d_sphs,
+                  void *d_sph_meta, double *gpu_ms, std::string &err);
+
 // host_util.cpp
 void set_global_error(const std::string &msg);
 const char *global_error();

@@ -890,7 +890,8 @@ struct rtgpu_ctx {
   int device = 0;
   std::string err;
   bool have_scene = false;
-  rtgpu_flat_scene host{};
+  mutable rtgpu_flat_scene host{};
+  mutable bool host_stale = false;  // rtgpu_refit changed the device arrays; host copy refreshed on demand
   void *d_nodes = nullptr, *d_tris = nullptr, *d_sphs = nullptr, *d_sph_meta = nullptr,
        *d_mats = nullptr;
   unsigned long long *d_counters = nullptr;
@@ -945,6 +946,7 @@ void free_scene_device(rtgpu_ctx *ctx) {
   ctx->d_nodes = ctx->d_tris = ctx->d_sphs = ctx->d_sph_meta = ctx->d_mats = nullptr;
   rtgpu::free_flat_scene(&ctx->host);
   ctx->have_scene = false;
+  ctx->host_stale = false;
 }
 
 int upload(rtgpu_ctx *ctx, void **dst, const void *src, size_t bytes) {
@@ -1127,8 +1129,51 @@ extern "C" int rtgpu_upload_scene_lbvh(rtgpu_ctx *ctx, const rtgpu_scene_desc *s
   return 0;
 }
 
+// New geometry (and material table) under the topology of the uploaded tree
+// (refit.hip).  The host copy of the flattened scene is refreshed lazily, by the
+// next rtgpu_get_flat_scene: a frame loop that refits every frame never pays for it.
+extern "C" int rtgpu_refit(rtgpu_ctx *ctx, const rtgpu_scene_desc *scene) {
+  if (!ctx) return 1;
+  if (!ctx->have_scene) { ctx->err = "no scene uploaded (call rtgpu_upload_scene first)"; return 1; }
+  if (rtgpu::validate_scene(scene, ctx->err)) return 1;
+  rtgpu_flat_scene &h = ctx->host;
+  if (scene->n_spheres != h.n_spheres || scene->n_triangles != h.n_tris || scene->n_materials != h.n_materials) {
+    ctx->err = "refit: the scene must hold the sphere, triangle and material counts of the uploaded one";
+    return 1;
+  }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  rtgpu_material *mats = rtgpu::flatten_materials(scene);
+  if (!mats) { ctx->err = "out of host memory for the material table"; return 2; }
+  std::free((void *)h.materials);
+  h.materials = mats;
+  if (h.n_materials)
+    HIP_TRY(ctx, hipMemcpy(ctx->d_mats, mats, h.n_materials * sizeof(rtgpu_material), hipMemcpyHostToDevice));
+  ctx->host_stale = true;
+  double ms = 0.0;
+  int rc = rtgpu::refit_device(scene, ctx->d_nodes, h.n_nodes, ctx->d_tris, ctx->d_sphs, ctx->d_sph_meta, &ms, ctx->err);
+  if (rc) {  // the device arrays may be half rewritten: the scene is gone
+    std::string keep = ctx->err;
+    free_scene_device(ctx);
+    ctx->err = keep + " (scene dropped, upload again)";
+    return rc;
+  }
+  h.build_ms = ms;
+  return 0;
+}
+
 extern "C" int rtgpu_get_flat_scene(const rtgpu_ctx *ctx, rtgpu_flat_scene *out) {
   if (!ctx || !out || !ctx->have_scene) return 1;
+  if (ctx->host_stale) {
+    const rtgpu_flat_scene &h = ctx->host;
+    if (hipSetDevice(ctx->device) != hipSuccess ||
+        hipMemcpy((void *)h.nodes, ctx->d_nodes, (size_t)h.n_nodes * sizeof(rtgpu_node), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy((void *)h.tris, ctx->d_tris, (size_t)h.n_tris * sizeof(rtgpu_tri), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy((void *)h.spheres, ctx->d_sphs, (size_t)h.n_spheres * sizeof(rtgpu_sph), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy((void *)h.sphere_meta, ctx->d_sph_meta, (size_t)h.n_spheres * 2 * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess)
+      return 2;
+    ctx->host_stale = false;
+  }
   *out = ctx->host;
   return 0;
 }

@@ -20,13 +20,24 @@ void rt_shutdown() {
   gRt_Ctx = nullptr;
 }
 
-void rt_scene_upload_or_panic(Scene const &scene) {
+static ::rtgpu_scene_desc desc_of(Scene const &scene) {
   ::rtgpu_scene_desc d = {};
   d.spheres   = (::rtgpu_sphere const *)scene.spheres;      d.n_spheres   = (uint64_t)scene.spheres_count;
   d.triangles = (::rtgpu_triangle const *)scene.triangles;  d.n_triangles = (uint64_t)scene.triangles_count;
   d.materials = (::rtgpu_material const *)scene.materials;  d.n_materials = (uint64_t)scene.materials_count;
+  return d;
+}
+
+void rt_scene_upload_or_panic(Scene const &scene) {
+  ::rtgpu_scene_desc d = desc_of(scene);
   if (::rtgpu_upload_scene(gRt_Ctx, &d) != 0)
     errf("rt: scene upload failed: %s", ::rtgpu_last_error(gRt_Ctx));
+}
+
+void rt_scene_refit_or_panic(Scene const &scene) {
+  ::rtgpu_scene_desc d = desc_of(scene);
+  if (::rtgpu_refit(gRt_Ctx, &d) != 0)
+    errf("rt: scene refit failed: %s", ::rtgpu_last_error(gRt_Ctx));
 }
 
 Camera rt_camera_look_at(Vec3 from, Vec3 at, Vec3 up, f32 vfov_deg, f32 aspect, f32 aperture,

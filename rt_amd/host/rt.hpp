@@ -76,6 +76,11 @@ void rt_init_or_panic(int device_index = 0);
 void rt_shutdown();
 
 void rt_scene_upload_or_panic(Scene const &scene);
+// Moved / edited primitives under the uploaded tree (same counts, primitive i
+// stays primitive i): boxes and leaf records are recomputed on the GPU, the
+// topology is kept.  For per-frame animation; upload again when the tree no
+// longer fits the geometry.
+void rt_scene_refit_or_panic(Scene const &scene);
 
 [[nodiscard]] Camera rt_camera_look_at(Vec3 from, Vec3 at, Vec3 up, f32 vfov_deg, f32 aspect,
                                        f32 aperture = 0.f, f32 focus_dist = 10.f);

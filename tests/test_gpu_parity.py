@@ -155,6 +155,10 @@ def test_edge_cases(ra, oracle, gpu_ctx):
         "mixed leaf": make_scene(ra, spheres=[(0, 0, 0, 1, 2), (0.1, 0, 0, 1, 1)],
                                  triangles=[((-2, -2, -1), (2, -2, -1), (0, 2, -1), 0)], materials=mats),
         "coincident": make_scene(ra, spheres=[(0, 0, 0, 1, 0)] * 40, materials=mats),
+        # 2..4 primitives of one type that SAH keeps in ONE leaf: root with an empty sibling
+        "two spheres, one leaf": make_scene(ra, spheres=[(0, 0, 0, 1, 0), (0.5, 0, 0, 1, 3)], materials=mats),
+        "four triangles, one leaf": make_scene(ra, triangles=[
+            ((-1, -1, 0.1 * k), (1, -1, 0.1 * k), (0, 1, 0.1 * k), k) for k in range(4)], materials=mats),
     }
     for name, sc in scenes.items():
         for (w, h) in ((33, 17), (64, 64)):            # ragged: not a multiple of the 8x8 block / tile

@@ -106,6 +106,13 @@ def test_flatten_tiny_scenes(ra, oracle):
     assert one.c.n_nodes == 1 and one.nodes_u32[0, 13] == 0xFFFFFFFF
     assert one.nodes_u32[0, 12] == 0x80000000 | 0x40000000  # leaf, sphere, count 1, first 0
     assert oracle.validate_bvh(one.c)[0] == 0
+    # 2..4 primitives of one type that SAH keeps together: one leaf under a root with an empty sibling
+    for k in (2, 3, 4):
+        few = ra.FlatScene.build(make_scene(ra, spheres=[(0.3 * i, 0, 0, 1, 0) for i in range(k)],
+                                            materials=[(0, .5, .5, .5, 0)]))
+        assert few.c.n_nodes == 1 and few.c.max_depth == 1 and few.nodes_u32[0, 13] == 0xFFFFFFFF
+        assert few.nodes_u32[0, 12] == 0x80000000 | 0x40000000 | ((k - 1) << 27)
+        assert np.all(np.isinf(few.nodes_f32[0, 6:12])) and oracle.validate_bvh(few.c) == (0, 1)
     # 64 coincident spheres: SAH cannot split them, median split must
     same = ra.FlatScene.build(make_scene(ra, spheres=[(0, 0, 0, 1, 0)] * 64, materials=[(0, .5, .5, .5, 0)]))
     assert oracle.validate_bvh(same.c)[0] == 0

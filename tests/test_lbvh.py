@@ -39,6 +39,9 @@ def _scenes(ra):
         "coincident": make_scene(ra, spheres=[(0, 0, 0, 1, 0)] * 40, materials=MATS),
         "collinear centroids": make_scene(ra, spheres=[(float(i), 0, 0, .4, i % 3) for i in range(33)], materials=MATS),
         "two": make_scene(ra, spheres=[(0, 0, 0, 1, 0)], triangles=[((-2, -2, -1), (2, -2, -1), (0, 2, -1), 1)], materials=MATS),
+        "one leaf of two": make_scene(ra, spheres=[(0, 0, 0, 1, 0), (0.5, 0, 0, 1, 1)], materials=MATS),
+        "one leaf of four": make_scene(ra, triangles=[((-1, -1, .1 * k), (1, -1, .1 * k), (0, 1, .1 * k), k % 3)
+                                                      for k in range(4)], materials=MATS),
         "one sphere": make_scene(ra, spheres=[(0, 0, 0, 1, 2)], materials=MATS),
         "one triangle": make_scene(ra, triangles=[((-1, -1, 0), (1, -1, 0), (0, 1, 0), 1)], materials=MATS),
         "empty": make_scene(ra, materials=MATS),
