@@ -195,7 +195,23 @@ void rtgpu_flat_scene_free(rtgpu_flat_scene *fs);
 int  rtgpu_render(rtgpu_ctx *ctx, const rtgpu_camera *cam, const rtgpu_settings *s,
                   float *accum_rgba, uint32_t *prim_id, rtgpu_stats *stats);
 
-/* Same, outputs in device memory of the context's GPU, launched on `stream`
+/* Non-blocking form of rtgpu_render, for a frame loop that must keep running
+ * while the frame is traced (the reference's loop pumps window messages every
+ * iteration, code/first.cpp:78-88, and its author wants tracing to go on while
+ * the window is minimised, code/window/wnd_proc.cxx:42-44; SURVEY.md §8b
+ * "blocking or begin/poll").  _begin queues the frame on a stream the context
+ * owns and returns; _poll sets *done without blocking; _end blocks until the
+ * frame is finished and copies it into the buffers given to _begin (which must
+ * stay valid until then; with RTGPU_FLAG_ACCUMULATE accum_rgba is also read by
+ * _begin).  One frame at a time: while a frame is pending every other call that
+ * renders, resolves through host buffers, uploads or refits returns an error.
+ * The three calls come from one thread, like everything else on a context. */
+int  rtgpu_render_begin(rtgpu_ctx *ctx, const rtgpu_camera *cam, const rtgpu_settings *s,
+                        float *accum_rgba, uint32_t *prim_id /* may be NULL */);
+int  rtgpu_render_poll(rtgpu_ctx *ctx, int *done);
+int  rtgpu_render_end(rtgpu_ctx *ctx, rtgpu_stats *stats /* may be NULL */);
+
+/* As rtgpu_render, outputs in device memory of the context's GPU, launched on `stream`
  * (a hipStream_t, NULL = default stream).  Asynchronous unless `stats` is
  * non-NULL (then it synchronises the stream to read the counters back). */
 int  rtgpu_render_device(rtgpu_ctx *ctx, const rtgpu_camera *cam, const rtgpu_settings *s,

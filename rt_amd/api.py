@@ -134,6 +134,9 @@ lib.rtgpu_flatten_scene_host.argtypes = [_P(SceneDesc), _P(FlatSceneC)]
 lib.rtgpu_flat_scene_free.argtypes = [_P(FlatSceneC)]
 lib.rtgpu_flat_scene_free.restype = None
 lib.rtgpu_render.argtypes = [C.c_void_p, _P(Camera), _P(Settings), C.c_void_p, C.c_void_p, _P(Stats)]
+lib.rtgpu_render_begin.argtypes = [C.c_void_p, _P(Camera), _P(Settings), C.c_void_p, C.c_void_p]
+lib.rtgpu_render_poll.argtypes = [C.c_void_p, _P(C.c_int)]
+lib.rtgpu_render_end.argtypes = [C.c_void_p, _P(Stats)]
 lib.rtgpu_render_device.argtypes = [
     C.c_void_p, _P(Camera), _P(Settings), C.c_void_p, C.c_void_p, C.c_void_p, _P(Stats)]
 lib.rtgpu_profile_counters.argtypes = [C.c_void_p, _P(C.c_uint64)]
@@ -361,6 +364,27 @@ class Context:
         self._check(lib.rtgpu_render(
             self._h, C.byref(cam), C.byref(s), accum.ctypes.data,
             ids.ctypes.data if ids is not None else None, C.byref(st) if want_stats else None))
+        return accum, ids, st
+
+    def render_begin(self, cam, settings, accum, ids=None):
+        """Non-blocking rtgpu_render_begin into caller-owned numpy buffers (kept alive here
+        until render_end)."""
+        assert accum.dtype == np.float32 and accum.flags.c_contiguous
+        assert ids is None or (ids.dtype == np.uint32 and ids.flags.c_contiguous)
+        self._check(lib.rtgpu_render_begin(self._h, C.byref(cam), C.byref(settings), accum.ctypes.data,
+                                           ids.ctypes.data if ids is not None else None))
+        self._pending = (accum, ids)
+
+    def render_poll(self):
+        done = C.c_int()
+        self._check(lib.rtgpu_render_poll(self._h, C.byref(done)))
+        return bool(done.value)
+
+    def render_end(self, want_stats=True):
+        st = Stats()
+        self._check(lib.rtgpu_render_end(self._h, C.byref(st) if want_stats else None))
+        accum, ids = getattr(self, "_pending", (None, None))
+        self._pending = None
         return accum, ids, st
 
     def render_device(self, cam, settings, accum_ptr, ids_ptr=None, stream=None, stats=None):

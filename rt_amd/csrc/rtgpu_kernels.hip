@@ -910,6 +910,13 @@ struct rtgpu_ctx {
   // grow-only staging for the host-pointer entry points
   void *d_accum = nullptr;  size_t d_accum_bytes = 0;
   void *d_ids = nullptr;    size_t d_ids_bytes = 0;
+  // rtgpu_render_begin / _poll / _end: the frame in flight on the context's own stream
+  hipStream_t stream = nullptr;
+  hipEvent_t ev_done = nullptr;
+  bool pending = false;
+  float *pend_accum = nullptr;
+  uint32_t *pend_ids = nullptr;
+  uint64_t pend_px = 0;
 };
 
 namespace {
@@ -960,6 +967,7 @@ int upload(rtgpu_ctx *ctx, void **dst, const void *src, size_t bytes) {
 int check_settings(rtgpu_ctx *ctx, const rtgpu_camera *cam, const rtgpu_settings *s,
                    uint32_t *ts_log2_out) {
   if (!cam || !s) { ctx->err = "camera or settings is NULL"; return 1; }
+  if (ctx->pending) { ctx->err = "a frame begun with rtgpu_render_begin is pending (call rtgpu_render_end)"; return 1; }
   if (!ctx->have_scene) { ctx->err = "no scene uploaded (call rtgpu_upload_scene first)"; return 1; }
   if (s->width == 0 || s->height == 0 || s->width > 65536u || s->height > 65536u) {
     ctx->err = "width/height must be in 1..65536"; return 1;
@@ -1000,7 +1008,9 @@ extern "C" int rtgpu_create(rtgpu_ctx **out, int device_index) {
   if ((e = hipSetDevice(device_index)) != hipSuccess ||
       (e = hipGetDeviceProperties(&prop, device_index)) != hipSuccess ||
       (e = hipMalloc((void **)&ctx->d_counters, 256)) != hipSuccess ||
-      (e = hipEventCreate(&ctx->ev0)) != hipSuccess || (e = hipEventCreate(&ctx->ev1)) != hipSuccess) {
+      (e = hipEventCreate(&ctx->ev0)) != hipSuccess || (e = hipEventCreate(&ctx->ev1)) != hipSuccess ||
+      (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
+      (e = hipEventCreateWithFlags(&ctx->ev_done, hipEventDisableTiming)) != hipSuccess) {
     rtgpu::set_global_error(std::string("rtgpu_create: ") + hipGetErrorString(e));
     rtgpu_destroy(ctx);
     return 2;
@@ -1052,6 +1062,7 @@ extern "C" int rtgpu_create(rtgpu_ctx **out, int device_index) {
 extern "C" void rtgpu_destroy(rtgpu_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
+  (void)hipDeviceSynchronize();  // a frame begun and never ended may still be running
   free_scene_device(ctx);
   (void)hipFree(ctx->d_counters);
   (void)hipFree(ctx->d_ovf);
@@ -1061,11 +1072,14 @@ extern "C" void rtgpu_destroy(rtgpu_ctx *ctx) {
   (void)hipFree(ctx->d_ids);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->ev_done) (void)hipEventDestroy(ctx->ev_done);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
 
 extern "C" int rtgpu_upload_scene(rtgpu_ctx *ctx, const rtgpu_scene_desc *scene) {
   if (!ctx) return 1;
+  if (ctx->pending) { ctx->err = "a frame begun with rtgpu_render_begin is pending (call rtgpu_render_end)"; return 1; }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipDeviceSynchronize());
   free_scene_device(ctx);
@@ -1091,6 +1105,7 @@ extern "C" int rtgpu_upload_scene(rtgpu_ctx *ctx, const rtgpu_scene_desc *scene)
 // (and with it the oracle) sees exactly what the kernels traverse.
 extern "C" int rtgpu_upload_scene_lbvh(rtgpu_ctx *ctx, const rtgpu_scene_desc *scene) {
   if (!ctx) return 1;
+  if (ctx->pending) { ctx->err = "a frame begun with rtgpu_render_begin is pending (call rtgpu_render_end)"; return 1; }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipDeviceSynchronize());
   free_scene_device(ctx);
@@ -1134,6 +1149,7 @@ extern "C" int rtgpu_upload_scene_lbvh(rtgpu_ctx *ctx, const rtgpu_scene_desc *s
 // next rtgpu_get_flat_scene: a frame loop that refits every frame never pays for it.
 extern "C" int rtgpu_refit(rtgpu_ctx *ctx, const rtgpu_scene_desc *scene) {
   if (!ctx) return 1;
+  if (ctx->pending) { ctx->err = "a frame begun with rtgpu_render_begin is pending (call rtgpu_render_end)"; return 1; }
   if (!ctx->have_scene) { ctx->err = "no scene uploaded (call rtgpu_upload_scene first)"; return 1; }
   if (rtgpu::validate_scene(scene, ctx->err)) return 1;
   rtgpu_flat_scene &h = ctx->host;
@@ -1204,6 +1220,7 @@ extern "C" int rtgpu_render_device(rtgpu_ctx *ctx, const rtgpu_camera *cam, cons
       ctx->planes_bytes = 0;
       HIP_TRY(ctx, hipMalloc((void **)&ctx->d_planes, want));
       HIP_TRY(ctx, hipMemset(ctx->d_planes, 0, want));
+      HIP_TRY(ctx, hipDeviceSynchronize());  // the memset runs on the null stream; `stream` may be non-blocking
       ctx->planes_bytes = want;
     }
   }
@@ -1414,6 +1431,67 @@ extern "C" int rtgpu_render(rtgpu_ctx *ctx, const rtgpu_camera *cam, const rtgpu
   return 0;
 }
 
+// Non-blocking form of rtgpu_render: the frame runs on the context's own stream
+// while the caller's loop keeps going (SURVEY.md §8b "blocking or begin/poll").
+extern "C" int rtgpu_render_begin(rtgpu_ctx *ctx, const rtgpu_camera *cam, const rtgpu_settings *s,
+                                  float *accum_rgba, uint32_t *prim_id) {
+  if (!ctx) return 1;
+  uint32_t ts_log2 = 0;
+  if (check_settings(ctx, cam, s, &ts_log2)) return 1;
+  if (!accum_rgba) { ctx->err = "accum output pointer is NULL"; return 1; }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  uint64_t n_px = (s->flags & RTGPU_FLAG_COMPACT)
+                      ? rtgpu_compact_pixels(s->width, s->height, s->tile_size, s->rank, s->world_size)
+                      : (uint64_t)s->width * s->height;
+  if (n_px) {
+    if (ensure(ctx, &ctx->d_accum, &ctx->d_accum_bytes, n_px * 16)) return 2;
+    if (prim_id && ensure(ctx, &ctx->d_ids, &ctx->d_ids_bytes, n_px * 4)) return 2;
+    if (s->flags & RTGPU_FLAG_ACCUMULATE)
+      HIP_TRY(ctx, hipMemcpyAsync(ctx->d_accum, accum_rgba, n_px * 16, hipMemcpyHostToDevice, ctx->stream));
+    else
+      HIP_TRY(ctx, hipMemsetAsync(ctx->d_accum, 0, n_px * 16, ctx->stream));
+    if (prim_id) HIP_TRY(ctx, hipMemsetAsync(ctx->d_ids, 0xFF, n_px * 4, ctx->stream));
+    int rc = rtgpu_render_device(ctx, cam, s, ctx->d_accum, prim_id ? ctx->d_ids : nullptr, ctx->stream, nullptr);
+    if (rc) { (void)hipStreamSynchronize(ctx->stream); return rc; }
+  }
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_done, ctx->stream));
+  ctx->pending = true;
+  ctx->pend_accum = accum_rgba;
+  ctx->pend_ids = prim_id;
+  ctx->pend_px = n_px;
+  return 0;
+}
+
+extern "C" int rtgpu_render_poll(rtgpu_ctx *ctx, int *done) {
+  if (!ctx || !done) return 1;
+  *done = 0;
+  if (!ctx->pending) { ctx->err = "no frame is pending (call rtgpu_render_begin first)"; return 1; }
+  hipError_t e = hipEventQuery(ctx->ev_done);
+  if (e == hipSuccess) { *done = 1; return 0; }
+  if (e == hipErrorNotReady) return 0;
+  hip_fail(ctx, e, "hipEventQuery");
+  return 2;
+}
+
+extern "C" int rtgpu_render_end(rtgpu_ctx *ctx, rtgpu_stats *stats) {
+  if (!ctx) return 1;
+  if (!ctx->pending) { ctx->err = "no frame is pending (call rtgpu_render_begin first)"; return 1; }
+  ctx->pending = false;  // whatever happens below, the frame is over
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipEventSynchronize(ctx->ev_done));
+  if (ctx->pend_px) {
+    HIP_TRY(ctx, hipMemcpy(ctx->pend_accum, ctx->d_accum, ctx->pend_px * 16, hipMemcpyDeviceToHost));
+    if (ctx->pend_ids) HIP_TRY(ctx, hipMemcpy(ctx->pend_ids, ctx->d_ids, ctx->pend_px * 4, hipMemcpyDeviceToHost));
+  }
+  if (stats) {
+    unsigned long long c[8];
+    HIP_TRY(ctx, hipMemcpy(c, ctx->d_counters, sizeof(c), hipMemcpyDeviceToHost));
+    stats->paths = c[1]; stats->rays = c[2]; stats->nodes = c[3];
+    stats->tri_tests = c[4]; stats->sphere_tests = c[5]; stats->scatters = c[6];
+  }
+  return 0;
+}
+
 extern "C" int rtgpu_resolve_rgba8_device(rtgpu_ctx *ctx, const void *d_accum_rgba, void *d_rgba8,
                                           uint64_t n_pixels, void *stream) {
   if (!ctx) return 1;
@@ -1431,6 +1509,7 @@ extern "C" int rtgpu_resolve_rgba8_device(rtgpu_ctx *ctx, const void *d_accum_rg
 extern "C" int rtgpu_resolve_rgba8(rtgpu_ctx *ctx, const float *accum_rgba, uint32_t *rgba8,
                                    uint64_t n_pixels) {
   if (!ctx) return 1;
+  if (ctx->pending) { ctx->err = "a frame begun with rtgpu_render_begin is pending (call rtgpu_render_end)"; return 1; }
   if (!accum_rgba || !rgba8) { ctx->err = "resolve: NULL pointer"; return 1; }
   if (n_pixels == 0) return 0;
   HIP_TRY(ctx, hipSetDevice(ctx->device));

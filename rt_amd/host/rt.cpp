@@ -59,6 +59,23 @@ void rt_render_or_panic(Camera const &cam, Render_Settings const &settings, Vec4
     errf("rt: render failed: %s", ::rtgpu_last_error(gRt_Ctx));
 }
 
+void rt_render_begin_or_panic(Camera const &cam, Render_Settings const &settings, Vec4 *accum_out,
+                              u32 *prim_id_out) {
+  if (::rtgpu_render_begin(gRt_Ctx, &cam, &settings, (float *)accum_out, prim_id_out) != 0)
+    errf("rt: render failed: %s", ::rtgpu_last_error(gRt_Ctx));
+}
+
+bool rt_render_done() {
+  int done = 0;
+  if (::rtgpu_render_poll(gRt_Ctx, &done) != 0) errf("rt: render failed: %s", ::rtgpu_last_error(gRt_Ctx));
+  return done != 0;
+}
+
+void rt_render_end_or_panic(Render_Stats *stats_out) {
+  if (::rtgpu_render_end(gRt_Ctx, stats_out) != 0)
+    errf("rt: render failed: %s", ::rtgpu_last_error(gRt_Ctx));
+}
+
 void rt_resolve_rgba8_or_panic(Vec4 const *accum, u32 *rgba8_out, s64 pixel_count) {
   if (::rtgpu_resolve_rgba8(gRt_Ctx, (float const *)accum, rgba8_out, (uint64_t)pixel_count) != 0)
     errf("rt: resolve failed: %s", ::rtgpu_last_error(gRt_Ctx));

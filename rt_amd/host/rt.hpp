@@ -93,6 +93,15 @@ void rt_scene_refit_or_panic(Scene const &scene);
 void rt_render_or_panic(Camera const &cam, Render_Settings const &settings, Vec4 *accum_out,
                         u32 *prim_id_out = nullptr, Render_Stats *stats_out = nullptr);
 
+// The same frame without blocking the loop (the message pump of
+// code/first.cpp:78-88 keeps running): begin, then once per loop iteration ask
+// rt_render_done(); when it says true, rt_render_end_or_panic() fills the buffers
+// given to begin.  One frame in flight; buffers stay valid until end.
+void rt_render_begin_or_panic(Camera const &cam, Render_Settings const &settings, Vec4 *accum_out,
+                              u32 *prim_id_out = nullptr);
+[[nodiscard]] bool rt_render_done();
+void rt_render_end_or_panic(Render_Stats *stats_out = nullptr);
+
 // accum -> 0xRRGGBBAA (gamma 2), ready for a B8G8R8A8/R8G8B8A8 upload.
 void rt_resolve_rgba8_or_panic(Vec4 const *accum, u32 *rgba8_out, s64 pixel_count);
 

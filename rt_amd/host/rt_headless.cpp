@@ -84,16 +84,21 @@ int main(int argc, char **argv) {
   Render_Settings settings = rt_default_settings(width, height, spp, depth);
   Render_Stats stats;
   auto t0 = std::chrono::steady_clock::now();
-  rt_render_or_panic(cam, settings, accum, nullptr, &stats);   // <- the one call of the frame loop
+  // The frame loop of code/first.cpp:78-88 with the trace in flight: begin once,
+  // keep "pumping messages" until the frame is done, then collect it.
+  rt_render_begin_or_panic(cam, settings, accum);
+  s64 pumped = 0;
+  while (!rt_render_done()) pumped++;  // win32_message_loop(); gfx_render(); would go here
+  rt_render_end_or_panic(&stats);
   double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   rt_resolve_rgba8_or_panic(accum, rgba, (s64)width * height);
 
   std::printf("scene %u: %llu spheres, %llu triangles; %ux%u, %u spp, depth %u\n", kind,
               (unsigned long long)builtin.n_spheres, (unsigned long long)builtin.n_triangles, width,
               height, spp, depth);
-  std::printf("%llu rays, kernel %.3f ms (%.1f Mrays/s), call %.3f ms incl. PCIe copies\n",
+  std::printf("%llu rays, kernel %.3f ms (%.1f Mrays/s), begin..end %.3f ms incl. PCIe copies, %lld loop iterations meanwhile\n",
               (unsigned long long)stats.rays, rt_last_kernel_ms(),
-              (double)stats.rays / (rt_last_kernel_ms() * 1e3), ms);
+              (double)stats.rays / (rt_last_kernel_ms() * 1e3), ms, (long long)pumped);
 
   rt_write_ppm_or_panic(out_path, rgba, width, height);  // where Present would be
   std::printf("wrote %s\n", out_path);

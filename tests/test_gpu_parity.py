@@ -383,3 +383,38 @@ def test_error_paths(ra, gpu_ctx):
     with pytest.raises(ra.RtgpuError, match="material"):
         fresh.upload(bad)
     fresh.close()
+
+
+def test_begin_poll_end_matches_the_blocking_call(ra, oracle, gpu_ctx):
+    """rtgpu_render_begin/_poll/_end (SURVEY.md §8b "blocking or begin/poll"): same frame
+    as rtgpu_render bit for bit, other calls refused while the frame is pending."""
+    import time
+    scene, cam = ra.Scene.builtin(0, aspect=16 / 9)
+    gpu_ctx.upload(scene)
+    st = ra.default_settings(320, 180, spp=5, max_depth=8, flags=ra.FLAG_STATS)
+    want, want_ids, want_stats = gpu_ctx.render(cam, st)
+    acc = np.zeros((180, 320, 4), np.float32)
+    ids = np.zeros((180, 320), np.uint32)
+    gpu_ctx.render_begin(cam, st, acc, ids)
+    for call in (lambda: gpu_ctx.render(cam, st), lambda: gpu_ctx.upload(scene), lambda: gpu_ctx.refit(scene),
+                 lambda: gpu_ctx.resolve(want), lambda: gpu_ctx.render_begin(cam, st, acc, ids)):
+        with pytest.raises(ra.RtgpuError, match="pending"):
+            call()
+    t0 = time.time()
+    while not gpu_ctx.render_poll():
+        assert time.time() - t0 < 30
+    a, i, s = gpu_ctx.render_end()
+    assert a is acc and np.array_equal(i, want_ids)
+    assert_bit_equal(a, want, "begin/poll/end")
+    assert s.as_dict() == want_stats.as_dict()
+    # progressive: the second frame adds to the first (accum is read by begin)
+    st2 = ra.default_settings(320, 180, spp=5, max_depth=8, sample_offset=5, flags=ra.FLAG_ACCUMULATE)
+    gpu_ctx.render_begin(cam, st2, acc)
+    gpu_ctx.render_end(want_stats=False)
+    both = want.copy()
+    gpu_ctx.render(cam, st2, accum=both)
+    assert_bit_equal(acc, both, "begin/end progressive")
+    for call in (gpu_ctx.render_poll, gpu_ctx.render_end):
+        with pytest.raises(ra.RtgpuError, match="no frame is pending"):
+            call()
+    gpu_ctx.render(cam, st)  # and the context is usable as before
