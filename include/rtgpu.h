@@ -42,12 +42,16 @@ extern "C" {
 enum {
   RTGPU_MAT_LAMBERTIAN = 0u, /* param unused                                  */
   RTGPU_MAT_METAL      = 1u, /* param = fuzz in [0,1]                         */
-  RTGPU_MAT_DIELECTRIC = 2u  /* param = index of refraction                   */
+  RTGPU_MAT_DIELECTRIC = 2u, /* param = index of refraction                   */
+  RTGPU_MAT_EMISSIVE   = 3u  /* a light: emits albedo * param from both faces
+                                and ends the path (nothing is scattered)       */
 };
 
 /* Material semantics follow the literature the reference cites
  * (notes/materials.md:3-5 -> "Ray Tracing in One Weekend"): a tagged POD, not a
- * class hierarchy.  32 bytes. */
+ * class hierarchy.  32 bytes.  The emissive type is the
+ * diffuse light of the same series ("The Next Week"); "Lights" is an item of the
+ * reference's plan (notes/plan.md:16). */
 typedef struct rtgpu_material {
   float    albedo[3];
   float    param;

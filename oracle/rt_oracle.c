@@ -497,6 +497,10 @@ static v3 trace_path(const job_t *J, uint32_t x, uint32_t y, uint32_t sample, ui
     v3 albedo = v3_from(m->albedo);
     v3 nd;
     cn->scatters++;
+    if (m->type == RTGPU_MAT_EMISSIVE) { /* a light ends the path with its radiance, from either face */
+      L = v3_mul(thr, v3_scale(albedo, m->param));
+      break;
+    }
     if (!scatter(m->type, m->param, r.d, n, &rng, &nd)) break; /* absorbed: L stays 0 */
     thr = v3_mul(thr, albedo);
     r.o = p;

@@ -48,7 +48,7 @@ FLAG_PROFILE = 8
 NO_HIT = 0xFFFFFFFF
 SCENE_SEED = 0x52545F31  # "RT_1" 
 
-MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC = 0, 1, 2
+MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_EMISSIVE = 0, 1, 2, 3
 
 MATERIAL_DTYPE = np.dtype(
     [("albedo", "<f4", (3,)), ("param", "<f4"), ("type", "<u4"), ("_pad", "<u4", (3,))]

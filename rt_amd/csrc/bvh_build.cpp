@@ -373,6 +373,14 @@ T *copy_out(const std::vector<T> &v, size_t min_elems = 1) {
 
 }  // namespace
 
+// a type the kernels do not know would be shaded as a dielectric without its
+// precomputed constants: reject it here
+static int check_materials(const rtgpu_scene_desc *scene, std::string &err) {
+  for (uint64_t i = 0; i < scene->n_materials; i++)
+    if (scene->materials[i].type > RTGPU_MAT_EMISSIVE) { err = "material type out of range"; return 1; }
+  return 0;
+}
+
 int validate_scene(const rtgpu_scene_desc *scene, std::string &err) {
   if (!scene) { err = "scene is NULL"; return 1; }
   if ((scene->n_spheres && !scene->spheres) || (scene->n_triangles && !scene->triangles) ||
@@ -388,6 +396,7 @@ int validate_scene(const rtgpu_scene_desc *scene, std::string &err) {
     err = "scene has primitives but no materials";
     return 1;
   }
+  if (check_materials(scene, err)) return 1;
   for (uint64_t i = 0; i < scene->n_spheres; i++) {
     const rtgpu_sphere &s = scene->spheres[i];
     if (s.material >= scene->n_materials) { err = "sphere material index out of range"; return 1; }
@@ -445,6 +454,7 @@ int flatten_scene(const rtgpu_scene_desc *scene, rtgpu_flat_scene *out, std::str
     err = "scene has primitives but no materials";
     return 1;
   }
+  if (check_materials(scene, err)) return 1;
   auto t0 = std::chrono::steady_clock::now();
 
   Builder B;

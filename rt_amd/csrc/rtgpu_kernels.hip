@@ -422,6 +422,10 @@ void trace_kernel(const KParams P) {
           sd = normalize(reflect(rd, n));
           if (param > 0.0f) sd = sd + ruv * param;
           absorbed = !(dot(sd, n) > 0.0f);
+        } else if (mtype == RTGPU_MAT_EMISSIVE) {
+          L = thr * (albedo * param);  // a light ends the path with its radiance, from either face
+          sd = n;
+          absorbed = true;
         } else {
           // 1/ior and Schlick's r0 per face come precomputed with the flattened
           // material (bvh_build.cpp): the same f32 operations, done once on the host

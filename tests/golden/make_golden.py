@@ -11,7 +11,8 @@ Two kinds of fixture, kept apart on purpose:
                   of the hot path that exists in the reference (SURVEY.md §8a
                   rows a9/a10), so it is the only part that CAN be pinned by it.
 
-  rng_kat.json, isect_kat.json, scatter_kat.json, s0_64x36.npz, checksums.json
+  rng_kat.json, isect_kat.json, scatter_kat.json, s0_64x36.npz, checksums.json,
+  lit_box_48x48.npz
                   outputs of THIS repo's CPU oracle (oracle/rt_oracle.c), for
                   which the reference has no counterpart ("parity unpinned",
                   SURVEY.md §8c).  They pin the oracle against regressions and
@@ -237,6 +238,20 @@ def make_images(o):
     print("wrote s0_64x36.npz, checksums.json")
 
 
+def make_lit_box(o):
+    # emissive materials (RTGPU_MAT_EMISSIVE): the lit box of tests/util.py, black sky
+    sys.path.insert(0, os.path.dirname(HERE))
+    from util import lit_box
+    scene, cam = lit_box(ra)
+    fs = ra.FlatScene.build(scene)
+    st = ra.default_settings(48, 48, spp=4, max_depth=8, sky_bottom=(0, 0, 0), sky_top=(0, 0, 0))
+    acc, ids, stats = o.render(fs.c, cam, st)
+    np.savez_compressed(os.path.join(HERE, "lit_box_48x48.npz"), ids=ids, accum_4spp=acc.view(np.uint32),
+                        stats=np.array([stats[k] for k in sorted(stats)], np.uint64),
+                        stats_keys=np.array(sorted(stats)))
+    print("wrote lit_box_48x48.npz")
+
+
 if __name__ == "__main__":
     o = Oracle()
     make_ref_math()
@@ -244,3 +259,4 @@ if __name__ == "__main__":
     make_isect(o)
     make_scatter(o)
     make_images(o)
+    make_lit_box(o)

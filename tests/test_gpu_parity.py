@@ -418,3 +418,40 @@ def test_begin_poll_end_matches_the_blocking_call(ra, oracle, gpu_ctx):
         with pytest.raises(ra.RtgpuError, match="no frame is pending"):
             call()
     gpu_ctx.render(cam, st)  # and the context is usable as before
+
+
+def test_emissive_materials(ra, oracle, gpu_ctx):
+    """RTGPU_MAT_EMISSIVE: the lit box under a black sky, against the committed fixture,
+    against the oracle at a larger size with both builders, and the x2 linearity of the
+    lights at full HD (a size the oracle is not run at)."""
+    from util import lit_box
+    black = dict(sky_bottom=(0, 0, 0), sky_top=(0, 0, 0))
+    scene, cam = lit_box(ra)
+    gpu_ctx.upload(scene)
+    g = np.load(f"{GOLDEN}/lit_box_48x48.npz")
+    st = ra.default_settings(48, 48, spp=4, max_depth=8, flags=ra.FLAG_STATS, **black)
+    a, ids, s = gpu_ctx.render(cam, st)
+    assert np.array_equal(ids, g["ids"]) and np.array_equal(bits(a), g["accum_4spp"])
+    assert [s.as_dict()[k] for k in sorted(s.as_dict())] == g["stats"].tolist()
+    for builder in ("sah", "lbvh"):
+        gpu_ctx.upload(scene, builder=builder)
+        st = ra.default_settings(200, 200, spp=3, max_depth=12, flags=ra.FLAG_STATS, **black)
+        a, ids, s = gpu_ctx.render(cam, st)
+        b, ib, sb = oracle.render(gpu_ctx.flat_scene().c, cam, st, threads=16)
+        assert np.array_equal(ids, ib), builder
+        assert_bit_equal(a, b, f"lit box / {builder}")
+        assert s.as_dict() == sb
+    gpu_ctx.upload(scene)
+    st = ra.default_settings(1920, 1080, spp=8, max_depth=8, **black)
+    cam_hd = ra.look_at((0, 2, 7.5), (0, 2, 0), vfov=38.0, aspect=16 / 9)
+    a1, _, _ = gpu_ctx.render(cam_hd, st, want_ids=False)
+    twice = ra.Scene(scene.spheres, scene.triangles, scene.materials.copy())
+    twice.materials["param"][[3, 6]] *= 2
+    gpu_ctx.upload(twice)
+    a2, _, _ = gpu_ctx.render(cam_hd, st, want_ids=False)
+    assert_bit_equal(a2[..., :3], a1[..., :3] * np.float32(2), "lights x2 at 1080p")
+    assert (a1[..., :3] > 0).mean() > 0.2
+    bad = make_scene(ra, spheres=[(0, 0, 0, 1, 0)], materials=[(7, .5, .5, .5, 0)])
+    for builder in ("sah", "lbvh"):
+        with pytest.raises(ra.RtgpuError, match="material type"):
+            gpu_ctx.upload(bad, builder=builder)

@@ -162,3 +162,52 @@ def test_deep_tree_traversal(ra, oracle):
     b, ib, _ = oracle.render(fs.c, cam, st, brute_force=True)
     assert np.array_equal(ia, ib) and (ia != ra.NO_HIT).any()
     assert_bit_equal(a, b, "deep tree")
+
+
+BLACK = dict(sky_bottom=(0, 0, 0), sky_top=(0, 0, 0))
+
+
+def test_emissive_materials(ra, oracle):
+    """RTGPU_MAT_EMISSIVE ("Lights", notes/plan.md:16): a light ends the path with
+    albedo * param from either face; nothing else emits under a black sky."""
+    from util import lit_box
+    scene, cam = lit_box(ra)
+    fs = ra.FlatScene.build(scene)
+    st = ra.default_settings(48, 48, spp=4, max_depth=8, **BLACK)
+    acc, ids, stats = oracle.render(fs.c, cam, st)
+    g = np.load(f"{GOLDEN}/lit_box_48x48.npz")
+    assert np.array_equal(ids, g["ids"]) and np.array_equal(bits(acc), g["accum_4spp"])
+    assert [stats[k] for k in sorted(stats)] == g["stats"].tolist()
+    # pixels whose primary hit is the small emissive sphere (prim id 2, material 6) hold
+    # exactly spp * albedo * param: throughput 1, and the product is one rounded multiply
+    acc1, ids1, _ = oracle.render(fs.c, cam, ra.default_settings(48, 48, spp=1, **BLACK))
+    direct = ids1 == 2
+    assert direct.sum() > 4
+    assert np.all(acc1[direct][:, :3] == np.float32([1.0, 0.5, 0.2]) * np.float32(2.0))
+    # BVH traversal vs exhaustive search with lights in the scene
+    b, ib, _ = oracle.render(fs.c, cam, st, brute_force=True)
+    assert np.array_equal(ids, ib)
+    assert_bit_equal(acc, b, "lit box: bvh vs brute force")
+    # linearity: scaling every light by 2 (exact in binary floating point) scales the frame by 2
+    twice = ra.Scene(scene.spheres, scene.triangles, scene.materials.copy())
+    twice.materials["param"][[3, 6]] *= 2
+    fs2 = ra.FlatScene.build(twice)  # keep the owner alive while its arrays are read
+    acc2, ids2, _ = oracle.render(fs2.c, cam, st)
+    assert np.array_equal(ids2, ids)
+    assert_bit_equal(acc2[..., :3], acc[..., :3] * np.float32(2), "lights x2")
+    # no light, black sky: nothing arrives anywhere; the lit frame is not black
+    dark = ra.Scene(scene.spheres, scene.triangles, scene.materials.copy())
+    dark.materials["param"][[3, 6]] = 0
+    fs0 = ra.FlatScene.build(dark)
+    acc0, _, _ = oracle.render(fs0.c, cam, st)
+    assert np.all(acc0[..., :3] == 0) and (acc[..., :3] > 0).mean() > 0.2
+    # seen from behind (camera above the ceiling light, looking down through it): it still emits
+    above = ra.look_at((0, 3.995, 0), (0, 0, 0), up=(0, 0, 1), vfov=20.0, aspect=1.0)
+    _, ids_b, _ = oracle.render(fs.c, above, ra.default_settings(8, 8, spp=1, **BLACK))
+    assert set(np.unique(ids_b)) <= {3 + 10, 3 + 11}  # the two light triangles (3 spheres come first)
+
+
+def test_unknown_material_type_is_rejected(ra):
+    bad = make_scene(ra, spheres=[(0, 0, 0, 1, 0)], materials=[(4, .5, .5, .5, 0)])
+    with pytest.raises(ra.RtgpuError, match="material type"):
+        ra.FlatScene.build(bad)

@@ -51,3 +51,27 @@ def make_scene(ra, spheres=(), triangles=(), materials=()):
     for i, (ty, r, g, b, p) in enumerate(materials):
         mm[i] = ((r, g, b), p, ty, (0, 0, 0))
     return ra.Scene(s, t, mm)
+
+
+def lit_box(ra, light_power=8.0, light_mat=3):
+    """A closed room of ten triangles lit by a two-triangle ceiling light and a small
+    emissive sphere, with a glass and a metal sphere inside (the "Lights" item of the
+    reference's plan, notes/plan.md:16).  Materials: 0 white, 1 red, 2 green lambertian,
+    3 light (emissive, albedo * light_power), 4 glass, 5 metal, 6 warm emissive.
+    Returns (scene, camera for a square image)."""
+    def quad(a, b, c, d, m):
+        return [(a, b, c, m), (a, c, d, m)]
+    L, H = 2.0, 2.0
+    tris = []
+    tris += quad((-L, 0, -L), (L, 0, -L), (L, 0, L), (-L, 0, L), 0)            # floor
+    tris += quad((-L, 2 * H, -L), (-L, 2 * H, L), (L, 2 * H, L), (L, 2 * H, -L), 0)  # ceiling
+    tris += quad((-L, 0, -L), (-L, 2 * H, -L), (L, 2 * H, -L), (L, 0, -L), 0)  # back wall
+    tris += quad((-L, 0, -L), (-L, 0, L), (-L, 2 * H, L), (-L, 2 * H, -L), 1)  # left, red
+    tris += quad((L, 0, -L), (L, 2 * H, -L), (L, 2 * H, L), (L, 0, L), 2)      # right, green
+    tris += quad((-0.7, 2 * H - 0.01, -0.7), (0.7, 2 * H - 0.01, -0.7), (0.7, 2 * H - 0.01, 0.7),
+                 (-0.7, 2 * H - 0.01, 0.7), light_mat)                          # ceiling light
+    spheres = [(-0.9, 0.8, -0.5, 0.8, 5), (0.9, 0.7, 0.6, 0.7, 4), (0.0, 0.25, 1.2, 0.25, 6)]
+    mats = [(0, .73, .73, .73, 0), (0, .65, .05, .05, 0), (0, .12, .45, .15, 0),
+            (3, 1.0, 0.9, 0.8, light_power), (2, 1, 1, 1, 1.5), (1, .8, .8, .8, 0.05), (3, 1.0, 0.5, 0.2, 2.0)]
+    cam = ra.look_at((0, 2, 7.5), (0, 2, 0), vfov=38.0, aspect=1.0)
+    return make_scene(ra, spheres=spheres, triangles=tris, materials=mats), cam
