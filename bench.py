@@ -32,8 +32,10 @@ VALU_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 vector (spec)
 VALU_ISSUE_PEAK_GINST = 614.4  # 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction
 
 
-def algorithmic_bytes(st, n_pixels):
-    return 64 * st["nodes"] + 48 * st["tri_tests"] + 16 * st["sphere_tests"] + 32 * st["scatters"] + 16 * n_pixels
+def algorithmic_bytes(st, n_pixels, node_bytes=64):
+    """node_bytes: 64 (the C2 tree, read from its LDS copy) or 48 (packed nodes of trees of
+    1366 nodes or more, include/rtgpu_format.h)."""
+    return node_bytes * st["nodes"] + 48 * st["tri_tests"] + 16 * st["sphere_tests"] + 32 * st["scatters"] + 16 * n_pixels
 
 
 def algorithmic_flops(st):
@@ -199,7 +201,7 @@ def main():
     if rank == 0:
         k_ms = sum(kernel_ms) / len(kernel_ms)
         n_px_rank = counts["paths"] // spp
-        abytes = algorithmic_bytes(counts, n_px_rank)
+        abytes = algorithmic_bytes(counts, n_px_rank, 48 if ctx.flat_scene().c.nodes48 else 64)
         aflops = algorithmic_flops(counts)
         achieved = abytes / (k_ms * 1e-3) / 1e9
         traffic, traffic_src, pmc = measured_traffic(W, H, args.spp, depth, world)

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define RTGPU_ABI_VERSION 2u
+#define RTGPU_ABI_VERSION 3u
 
 /* ---- scene description (host side, caller-owned) ------------------------ */
 
@@ -149,6 +149,9 @@ typedef struct rtgpu_flat_scene {
   uint32_t       max_depth;    /* deepest leaf (root = 0)           */
   uint32_t       _pad;
   double         build_ms;
+  const void    *nodes48;      /* n_nodes packed nodes of 48 B (rtgpu_format.h) when
+                                  n_nodes >= RTGPU_NODE48_MIN_NODES, else NULL: the
+                                  array the trace loop traverses when present     */
 } rtgpu_flat_scene;
 
 typedef struct rtgpu_ctx rtgpu_ctx;

@@ -22,6 +22,33 @@ typedef struct rtgpu_node {
   uint32_t _pad[2];
 } rtgpu_node;
 
+/* Packed BVH2 node, 48 bytes, 16-byte aligned: the form the trace loop reads for
+ * trees of RTGPU_NODE48_MIN_NODES nodes or more (the ones it cannot keep in LDS).
+ * Every node fetch of such a tree goes through the texture path, whose cost is per
+ * load instruction: 48 bytes are three 16-byte loads instead of four.
+ * The twelve planes keep the order of rtgpu_node (word w: 0-2 lo0, 3-5 hi0, 6-8 lo1,
+ * 9-11 hi1); the two child references ride in the LOW BYTES of eight of them:
+ *   byte k of child0 = low byte of word k      (k = 0..3: lo0.x lo0.y lo0.z hi0.x)
+ *   byte k of child1 = low byte of word 8 + k  (k = 0..3: lo1.z hi1.x hi1.y hi1.z)
+ * and each of those eight planes is moved to the NEAREST float that carries its
+ * byte on the conservative side: a lo plane becomes the largest float <= the exact
+ * plane, a hi plane the smallest float >= it (at most 255 floats away, 511 where
+ * the move crosses zero among the denormals: the box grows by < 3.1e-5 of the
+ * plane's magnitude on those eight planes).
+ * The float AS STORED is the plane: nothing is masked before the slab test.  Words
+ * 4-7 (hi0.y hi0.z lo1.x lo1.y) are the exact planes.  Both the kernels and the
+ * oracle traverse this array when it is present, so hits and counters stay
+ * comparable bit for bit.  A tree with a non-finite plane (the empty child of a
+ * scene that fits one leaf) has no packed form; such trees are far below the
+ * threshold. */
+typedef struct rtgpu_node48 {
+  uint32_t w[12];
+#ifdef RTGPU_EXP_NODE48_STRIDE64  /* experiment only: packed words in 64-byte slots */
+  uint32_t exp_pad[4];
+#endif
+} rtgpu_node48;
+#define RTGPU_NODE48_MIN_NODES 1366u
+
 /* Child reference (also the traversal-stack entry):
  *   bit 31 = 0 : inner node, bits 0..30 = node index
  *   bit 31 = 1 : leaf; bit 30 = 1 sphere / 0 triangle;

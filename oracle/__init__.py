@@ -60,6 +60,7 @@ def load():
     lib.rto_validate_bvh.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
     lib.rto_build_lbvh.argtypes = [C.c_void_p, C.c_void_p]
     lib.rto_refit.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.rto_pack_node48.argtypes = [C.c_void_p, C.c_void_p]
     lib.rto_flat_free.argtypes = [C.c_void_p]
     lib.rto_flat_free.restype = None
     lib.rto_has_openmp.restype = C.c_int
@@ -131,6 +132,13 @@ class Oracle:
         if rc:
             raise RuntimeError(f"rto_build_lbvh failed with {rc}")
         return fs
+
+    def pack_node48(self, node_words):
+        """node_words: 16 u32 of one rtgpu_node -> 12 u32 of its packed form, or None."""
+        import numpy as np
+        src = np.ascontiguousarray(node_words, np.uint32)
+        out = np.zeros(12, np.uint32)
+        return out if self.lib.rto_pack_node48(src.ctypes.data, out.ctypes.data) else None
 
     def refit(self, flat_c, scene_desc):
         """CPU restatement of the GPU refit: same topology, geometry and materials of

@@ -224,6 +224,7 @@ RTO_API int rto_kat_tri(const float *o, const float *d, const float *v0, const f
 
 typedef struct {
   const rtgpu_node *nodes;
+  const rtgpu_node48 *nodes48; /* packed form (rtgpu_format.h); traversed instead of nodes when present */
   const rtgpu_tri *tris;
   const rtgpu_sph *sphs;
   const uint32_t *sph_meta;
@@ -285,22 +286,38 @@ static hit_t intersect_bvh(const scene_t *sc, const ray_t *r, float tmin, counte
     if (cur & RTGPU_REF_LEAF) {
       leaf_intersect(sc, r, cur, tmin, &best, cn);
     } else {
-      const rtgpu_node *n = &sc->nodes[cur];
       float tn0, tn1;
+      int h0, h1;
+      uint32_t c0, c1;
       cn->nodes++;
-      /* an empty child (scenes of < 2 primitives) has its box at +inf: its slab
-       * interval is [+inf,+inf] or [-inf,-inf] per axis and best.t <= FLT_MAX,
-       * so it never passes */
-      int h0 = slab(r, n->lo0, n->hi0, tmin, best.t, &tn0);
-      int h1 = slab(r, n->lo1, n->hi1, tmin, best.t, &tn1);
+      if (sc->nodes48) {
+        /* packed node: the twelve words ARE the planes (eight of them carry a byte of
+         * a child reference in their low byte and were moved to the conservative side
+         * by the packer); child k's reference = the low bytes of words 8k .. 8k+3 */
+        const uint32_t *w = sc->nodes48[cur].w;
+        float pl[12];
+        memcpy(pl, w, sizeof(pl));
+        c0 = (w[0] & 0xFFu) | ((w[1] & 0xFFu) << 8) | ((w[2] & 0xFFu) << 16) | ((w[3] & 0xFFu) << 24);
+        c1 = (w[8] & 0xFFu) | ((w[9] & 0xFFu) << 8) | ((w[10] & 0xFFu) << 16) | ((w[11] & 0xFFu) << 24);
+        h0 = slab(r, pl + 0, pl + 3, tmin, best.t, &tn0);
+        h1 = slab(r, pl + 6, pl + 9, tmin, best.t, &tn1);
+      } else {
+        const rtgpu_node *n = &sc->nodes[cur];
+        /* an empty child (scenes of < 2 primitives) has its box at +inf: its slab
+         * interval is [+inf,+inf] or [-inf,-inf] per axis and best.t <= FLT_MAX,
+         * so it never passes */
+        c0 = n->child0; c1 = n->child1;
+        h0 = slab(r, n->lo0, n->hi0, tmin, best.t, &tn0);
+        h1 = slab(r, n->lo1, n->hi1, tmin, best.t, &tn1);
+      }
       if (h0 && h1) {
-        if (tn1 < tn0) { stack[sp++] = n->child0; cur = n->child1; }
-        else           { stack[sp++] = n->child1; cur = n->child0; }
+        if (tn1 < tn0) { stack[sp++] = c0; cur = c1; }
+        else           { stack[sp++] = c1; cur = c0; }
         if (sp > g_max_stack) g_max_stack = sp;
         continue;
       }
-      if (h0) { cur = n->child0; continue; }
-      if (h1) { cur = n->child1; continue; }
+      if (h0) { cur = c0; continue; }
+      if (h1) { cur = c1; continue; }
     }
     if (sp == 0) break;
     cur = stack[--sp];
@@ -525,6 +542,7 @@ RTO_API int rto_render(const rtgpu_flat_scene *fs, const rtgpu_camera *cam, cons
                        uint32_t x1, uint32_t y1, int brute_force, int nthreads) {
   scene_t sc;
   sc.nodes = (const rtgpu_node *)fs->nodes;
+  sc.nodes48 = (const rtgpu_node48 *)fs->nodes48;
   sc.tris = (const rtgpu_tri *)fs->tris;
   sc.sphs = (const rtgpu_sph *)fs->spheres;
   sc.sph_meta = fs->sphere_meta;
@@ -687,6 +705,29 @@ RTO_API int rto_validate_bvh(const rtgpu_flat_scene *fs, uint32_t *max_depth_out
     for (uint64_t i = 0; i < fs->n_tris; i++) if (seen_t[i] != 1) { rc = 9; break; }
     for (uint64_t i = 0; i < fs->n_spheres; i++) if (seen_s[i] != 1) { rc = 9; break; }
   }
+  /* packed copy: present exactly from the threshold up; same references; every plane
+   * on the conservative side of the exact one and within 255 floats of it (511 across zero) */
+  if (!rc && ((fs->nodes48 != NULL) != (fs->n_nodes >= RTGPU_NODE48_MIN_NODES))) rc = 10;
+  if (!rc && fs->nodes48) {
+    const rtgpu_node48 *pk = (const rtgpu_node48 *)fs->nodes48;
+    for (uint64_t i = 0; i < fs->n_nodes && !rc; i++) {
+      const uint32_t *w = pk[i].w;
+      uint32_t x[12];
+      memcpy(x, nodes[i].lo0, 12);  memcpy(x + 3, nodes[i].hi0, 12);
+      memcpy(x + 6, nodes[i].lo1, 12);  memcpy(x + 9, nodes[i].hi1, 12);
+      uint32_t c0 = (w[0] & 0xFFu) | ((w[1] & 0xFFu) << 8) | ((w[2] & 0xFFu) << 16) | ((w[3] & 0xFFu) << 24);
+      uint32_t c1 = (w[8] & 0xFFu) | ((w[9] & 0xFFu) << 8) | ((w[10] & 0xFFu) << 16) | ((w[11] & 0xFFu) << 24);
+      if (c0 != nodes[i].child0 || c1 != nodes[i].child1) { rc = 11; break; }
+      for (int k = 0; k < 12; k++) {
+        int is_lo = (k % 6) < 3; /* words 0-2 and 6-8 are lo planes */
+        int64_t a = (w[k] & 0x80000000u) ? -(int64_t)(w[k] & 0x7FFFFFFFu) - 1 : (int64_t)w[k];  /* ordered: -0 just below +0 */
+        int64_t b = (x[k] & 0x80000000u) ? -(int64_t)(x[k] & 0x7FFFFFFFu) - 1 : (int64_t)x[k];
+        int moved = k < 4 || k >= 8;
+        int64_t lim = ((w[k] ^ x[k]) & 0x80000000u) ? 511 : 255; /* the low byte flips meaning across zero */
+        if (!moved ? a != b : (is_lo ? (a > b || b - a > lim) : (a < b || a - b > lim))) { rc = 12; break; }
+      }
+    }
+  }
   if (max_depth_out) *max_depth_out = maxd;
   free(seen_t); free(seen_s); free(stack);
   return rc;
@@ -698,6 +739,74 @@ RTO_API int rto_has_openmp(void) {
 #else
   return 0;
 #endif
+}
+
+/* ==== Packed 48-byte nodes (include/rtgpu_format.h) =================================
+ *
+ * CPU restatement of rt_amd/csrc/pack48.h (no reference counterpart: the reference
+ * has no BVH).  A child reference's four bytes ride in the low bytes
+ * of four planes; each such plane moves to the nearest float on the conservative
+ * side (lo planes down, hi planes up) whose low byte is the wanted one.  Written
+ * with float comparisons and nextafter-free bit stepping on magnitudes, i.e. NOT
+ * the ordered-integer formulation of the product, so that the two check each other. */
+static int pack_plane(uint32_t bits, uint32_t byte, int down, uint32_t *out) {
+  if ((bits & 0x7F800000u) == 0x7F800000u) return 0;
+  float x;
+  memcpy(&x, &bits, 4);
+  /* candidates: the same 256-float block with the byte swapped in, and the two
+   * neighbouring blocks in magnitude (same sign); across zero: the other sign's
+   * block of smallest magnitude.  Pick the conservative one nearest to x. */
+  uint32_t sign = bits & 0x80000000u, mag = bits & 0x7FFFFFFFu;
+  uint32_t cand[4];
+  int nc = 0;
+  cand[nc++] = sign | (mag & 0x7FFFFF00u) | byte;
+  if ((mag >> 8) < 0x7FFFFFu) cand[nc++] = sign | (((mag >> 8) + 1u) << 8) | byte;
+  if ((mag >> 8) > 0u) cand[nc++] = sign | (((mag >> 8) - 1u) << 8) | byte;
+  else cand[nc++] = (sign ^ 0x80000000u) | byte; /* block 0 of the other sign */
+  int have = 0;
+  float best = 0.0f;
+  uint32_t best_bits = 0;
+  for (int i = 0; i < nc; i++) {
+    if ((cand[i] & 0x7F800000u) == 0x7F800000u) continue;
+    float c;
+    memcpy(&c, &cand[i], 4);
+    /* total order on bit patterns where -0 < +0 (the product's ordered integers):
+     * compare as floats first, break the +-0 tie by sign */
+    int le = c < x || (c == x && ((cand[i] >> 31) >= (bits >> 31)));
+    int ge = c > x || (c == x && ((cand[i] >> 31) <= (bits >> 31)));
+    if (down ? !le : !ge) continue;
+    int closer = !have || (down ? (c > best || (c == best && (cand[i] >> 31) < (best_bits >> 31)))
+                                : (c < best || (c == best && (cand[i] >> 31) > (best_bits >> 31))));
+    if (closer) { have = 1; best = c; best_bits = cand[i]; }
+  }
+  if (!have) return 0;
+  *out = best_bits;
+  return 1;
+}
+
+RTO_API int rto_pack_node48(const rtgpu_node *n, rtgpu_node48 *out) {
+  uint32_t w[12];
+  memcpy(w, n->lo0, 12);  memcpy(w + 3, n->hi0, 12);
+  memcpy(w + 6, n->lo1, 12);  memcpy(w + 9, n->hi1, 12);
+  for (int i = 0; i < 12; i++)
+    if ((w[i] & 0x7F800000u) == 0x7F800000u) return 0;
+  for (int k = 0; k < 4; k++) {
+    if (!pack_plane(w[k], (n->child0 >> (8 * k)) & 0xFFu, k < 3, &w[k])) return 0;
+    if (!pack_plane(w[8 + k], (n->child1 >> (8 * k)) & 0xFFu, k < 1, &w[8 + k])) return 0;
+  }
+  memcpy(out->w, w, sizeof(w));
+  return 1;
+}
+
+/* nodes48 of a flattened scene, as the flattener adds it: NULL below the threshold */
+static rtgpu_node48 *pack_all(const rtgpu_node *nodes, uint64_t n, int *fail) {
+  *fail = 0;
+  if (n < RTGPU_NODE48_MIN_NODES) return NULL;
+  rtgpu_node48 *out = calloc((size_t)n, sizeof(rtgpu_node48));
+  if (!out) { *fail = 1; return NULL; }
+  for (uint64_t i = 0; i < n; i++)
+    if (!rto_pack_node48(&nodes[i], &out[i])) { free(out); *fail = 1; return NULL; }
+  return out;
 }
 
 /* ==== LBVH builder restatement ================================
@@ -774,7 +883,7 @@ static inline int lbvh_delta(const uint64_t *keys, int64_t n, int64_t a, int64_t
 RTO_API void rto_flat_free(rtgpu_flat_scene *fs) {
   if (!fs) return;
   free((void *)fs->nodes); free((void *)fs->tris); free((void *)fs->spheres);
-  free((void *)fs->sphere_meta); free((void *)fs->materials);
+  free((void *)fs->sphere_meta); free((void *)fs->materials); free((void *)fs->nodes48);
   memset(fs, 0, sizeof(*fs));
 }
 
@@ -954,6 +1063,9 @@ RTO_API int rto_build_lbvh(const rtgpu_scene_desc *sc, rtgpu_flat_scene *out) {
   out->sphere_meta = meta;
   out->materials = mats; out->n_materials = sc->n_materials;
   out->max_depth = max_depth;
+  int pfail;
+  out->nodes48 = pack_all(nodes, (uint64_t)n_inner, &pfail);
+  if (pfail) return 4;
   return 0;
 }
 
@@ -1062,5 +1174,8 @@ RTO_API int rto_refit(const rtgpu_flat_scene *in, const rtgpu_scene_desc *sc, rt
   out->sphere_meta = meta;
   out->materials = mats; out->n_materials = sc->n_materials;
   out->max_depth = in->max_depth;
+  int pfail;
+  out->nodes48 = pack_all(nodes, in->n_nodes, &pfail);
+  if (pfail) return 4;
   return 0;
 }

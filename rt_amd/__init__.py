@@ -27,5 +27,10 @@ from .api import (  # noqa: F401
     FLAG_STATS,
     FLAG_PROFILE,
     NO_HIT,
+    NODE48_MIN_NODES,
+    MAT_LAMBERTIAN,
+    MAT_METAL,
+    MAT_DIELECTRIC,
+    MAT_EMISSIVE,
     SCENE_SEED,
 )

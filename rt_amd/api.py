@@ -49,6 +49,7 @@ NO_HIT = 0xFFFFFFFF
 SCENE_SEED = 0x52545F31  # "RT_1" 
 
 MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_EMISSIVE = 0, 1, 2, 3
+NODE48_MIN_NODES = 1366
 
 MATERIAL_DTYPE = np.dtype(
     [("albedo", "<f4", (3,)), ("param", "<f4"), ("type", "<u4"), ("_pad", "<u4", (3,))]
@@ -115,6 +116,7 @@ class FlatSceneC(C.Structure):
         ("materials", C.c_void_p), ("n_materials", C.c_uint64),
         ("max_depth", C.c_uint32), ("_pad", C.c_uint32),
         ("build_ms", C.c_double),
+        ("nodes48", C.c_void_p),
     ]
 
 
@@ -282,6 +284,13 @@ class FlatScene:
     @property
     def nodes_u32(self):
         return self._view(self.c.nodes, self.c.n_nodes, np.uint32, 16)
+
+    @property
+    def nodes48_u32(self):
+        """Packed 48-byte nodes (12 words each); empty below RTGPU_NODE48_MIN_NODES."""
+        if not self.c.nodes48:
+            return np.zeros((0, 12), np.uint32)
+        return self._view(self.c.nodes48, self.c.n_nodes, np.uint32, 12)
 
     @property
     def tris_f32(self):

@@ -9,6 +9,7 @@
 // task decomposition (struct Builder), so the same scene always flattens to the
 // same bytes (the oracle walks these bytes).
 #include "rtgpu_internal.h"
+#include "pack48.h"
 
 #include <algorithm>
 #include <chrono>
@@ -437,6 +438,22 @@ rtgpu_material *flatten_materials(const rtgpu_scene_desc *scene) {
   return copy_out(mats);
 }
 
+// nodes -> packed 48-byte nodes (include/rtgpu_format.h), malloc'ed and 64-byte
+// aligned; NULL with err set if a plane is not finite (or on out-of-memory).
+rtgpu_node48 *pack_nodes48(const rtgpu_node *nodes, uint64_t n, std::string &err) {
+  size_t bytes = ((size_t)n * sizeof(rtgpu_node48) + 63) / 64 * 64;
+  rtgpu_node48 *out = (rtgpu_node48 *)std::aligned_alloc(64, bytes ? bytes : 64);
+  if (!out) { err = "out of host memory for the packed nodes"; return nullptr; }
+  std::memset(out, 0, bytes ? bytes : 64);
+  for (uint64_t i = 0; i < n; i++)
+    if (!pack_node48(nodes[i], &out[i])) {
+      std::free(out);
+      err = "a box plane is not finite or too close to FLT_MAX for the packed node format";
+      return nullptr;
+    }
+  return out;
+}
+
 int flatten_scene(const rtgpu_scene_desc *scene, rtgpu_flat_scene *out, std::string &err) {
   std::memset(out, 0, sizeof(*out));
   read_sah_env();
@@ -611,6 +628,10 @@ int flatten_scene(const rtgpu_scene_desc *scene, rtgpu_flat_scene *out, std::str
     err = "out of host memory while flattening the scene";
     return 1;
   }
+  if (out->n_nodes >= RTGPU_NODE48_MIN_NODES) {
+    out->nodes48 = pack_nodes48((const rtgpu_node *)out->nodes, out->n_nodes, err);
+    if (!out->nodes48) { free_flat_scene(out); return 1; }
+  }
   out->build_ms =
       std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   return 0;
@@ -623,6 +644,7 @@ void free_flat_scene(rtgpu_flat_scene *fs) {
   std::free((void *)fs->spheres);
   std::free((void *)fs->sphere_meta);
   std::free((void *)fs->materials);
+  std::free((void *)fs->nodes48);
   std::memset(fs, 0, sizeof(*fs));
 }
 
@@ -637,3 +659,13 @@ extern "C" int rtgpu_flatten_scene_host(const rtgpu_scene_desc *scene, rtgpu_fla
 }
 
 extern "C" void rtgpu_flat_scene_free(rtgpu_flat_scene *fs) { rtgpu::free_flat_scene(fs); }
+
+// Diagnostics (not in the public header): one node through the packer of pack48.h.
+extern "C" int rtgpu_debug_pack_node48(const void *node64, void *node48) {
+  rtgpu_node n;
+  std::memcpy(&n, node64, sizeof(n));
+  rtgpu_node48 p;
+  if (!rtgpu::pack_node48(n, &p)) return 1;
+  std::memcpy(node48, &p, sizeof(p));
+  return 0;
+}

@@ -1,0 +1,47 @@
+// pack48.hip — the packed 48-byte nodes (include/rtgpu_format.h) made on the GPU
+// from the 64-byte nodes, for trees that are built (lbvh_build.hip) or refitted
+// (refit.hip) there.  Same function as the host builder's (pack48.h), one node per
+// thread.  No reference counterpart (the reference has no BVH).
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "pack48.h"
+#include "rtgpu_internal.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void pack48_kernel(const rtgpu_node *nodes, uint32_t n, rtgpu_node48 *out,
+                                                     uint32_t *bad) {
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+    rtgpu_node48 p;
+    if (rtgpu::pack_node48(nodes[i], &p)) out[i] = p;
+    else atomicOr(bad, 1u);
+  }
+}
+
+}  // namespace
+
+namespace rtgpu {
+
+// The current device must be the context's.  Synchronous.
+int pack_nodes48_device(const void *d_nodes, uint64_t n, void *d_nodes48, std::string &err) {
+  if (n == 0) return 0;
+  uint32_t *d_bad = nullptr, bad = 0;
+  hipError_t e = hipMalloc((void **)&d_bad, sizeof(uint32_t));
+  if (e == hipSuccess) e = hipMemset(d_bad, 0, sizeof(uint32_t));
+  if (e == hipSuccess) {
+    unsigned blocks = (unsigned)((n + 255) / 256);
+    if (blocks > 8192u) blocks = 8192u;
+    hipLaunchKernelGGL(pack48_kernel, dim3(blocks), dim3(256), 0, 0, (const rtgpu_node *)d_nodes, (uint32_t)n,
+                       (rtgpu_node48 *)d_nodes48, d_bad);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpy(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost);
+  (void)hipFree(d_bad);
+  if (e != hipSuccess) { err = std::string("pack48: ") + hipGetErrorString(e); return 2; }
+  if (bad) { err = "a box plane is not finite or too close to FLT_MAX for the packed node format"; return 1; }
+  return 0;
+}
+
+}  // namespace rtgpu

@@ -16,6 +16,10 @@ void free_flat_scene(rtgpu_flat_scene *fs);
 int  validate_scene(const rtgpu_scene_desc *scene, std::string &err);
 // the caller's materials + the precomputed dielectric constants; malloc'ed, 64-byte aligned
 rtgpu_material *flatten_materials(const rtgpu_scene_desc *scene);
+// 64-byte nodes -> packed 48-byte nodes (malloc'ed; NULL + err if a plane is not finite)
+rtgpu_node48 *pack_nodes48(const rtgpu_node *nodes, uint64_t n, std::string &err);
+// pack48.hip: the same on the device (d_bad: one u32, set non-zero if a node has no packed form)
+int  pack_nodes48_device(const void *d_nodes, uint64_t n, void *d_nodes48, std::string &err);
 
 // lbvh_build.hip: the same flattened scene built on the GPU (device arrays, caller frees with free_lbvh)
 struct LbvhDevice {

@@ -283,11 +283,13 @@ __device__ __forceinline__ void wave_tick(unsigned lane, unsigned long long &c) 
 // MODE 0: the stack may overflow into global memory; 1: the whole stack fits in LDS;
 // 2: as 1, and the WHOLE tree (<= kSmallNodes nodes) is in the LDS node cache with its
 // four planes a compile-time distance apart, so a node fetch is one address and four
-// ds_read with immediate offsets, and no "cached or not" test.
+// ds_read with immediate offsets, and no "cached or not" test.  3 and 4: as 0 and 1 with
+// the packed 48-byte nodes (rtgpu_format.h): three loads per node step instead of four -
+// on these trees the texture path is the bound and it is paid per load instruction.
 template <int STATS, int REFILL, int MODE>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RTGPU_WAVES_PER_EU, RTGPU_WAVES_PER_EU)))
 void trace_kernel(const KParams P) {
-  constexpr bool LDS_ONLY = MODE >= 1, SMALL = MODE == 2;
+  constexpr bool LDS_ONLY = MODE == 1 || MODE == 2 || MODE == 4, SMALL = MODE == 2, PACKED = MODE >= 3;
   // LDS: [traversal stacks: stack_lds x kBlock u32][node cache: 4 planes x n_cached float4]
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   uint32_t *const lds_stack = smem;
@@ -362,6 +364,9 @@ void trace_kernel(const KParams P) {
 #define SECTION_END(acc) do { if (STATS == 2) { long long t_ = (long long)clock64(); acc += t_ - c_mark; c_mark = t_; } } while (0)
   if (STATS == 2) c_mark = (long long)clock64();
 
+#ifdef RTGPU_EXP_EXTRA_LOADS
+  float exp_dummy = 0.f;
+#endif
   for (;;) {
     // ---- (1) shade the rays whose traversal has finished (rows a6, a8) ----------
     if (STATS == 2) wave_tick(lane, w_outer);
@@ -655,6 +660,7 @@ void trace_kernel(const KParams P) {
           if ((int)cur >= 0) {
             if (STATS == 2) wave_tick(lane, w_node);
             float4 q0, q1, q2, q3;
+            uint32_t c0, c1;
             // MODE 0/1 (tree larger than the LDS cache) fetch every node through L1: a
             // partial cache measured no gain on the big scenes and costs a
             // test and two branches per step
@@ -665,9 +671,36 @@ void trace_kernel(const KParams P) {
               q1 = make_float4(w1.x, w1.y, w1.z, w1.w);
               q2 = make_float4(w2.x, w2.y, w2.z, w2.w);
               q3 = make_float4(w3.x, w3.y, w3.z, w3.w);
+              c0 = __float_as_uint(q3.x); c1 = __float_as_uint(q3.y);
+            } else if (PACKED) {
+              // 48-byte node at cur * 48 = (cur * 3) << 4; the child references are the low
+              // bytes of q0's and q2's four planes, gathered with three v_perm_b32 each
+              uint32_t c3;
+              asm("v_lshl_add_u32 %0, %1, 1, %1" : "=v"(c3) : "v"(cur));
+#ifdef RTGPU_EXP_NODE48_STRIDE64
+              const float4 *n = (const float4 *)(nodes_base + (cur << 6));
+#else
+              const float4 *n = (const float4 *)(nodes_base + (c3 << 4));
+#endif
+              q0 = n[0]; q1 = n[1]; q2 = n[2];
+              q3 = q2;
+              const uint32_t a0 = __builtin_amdgcn_perm(__float_as_uint(q0.y), __float_as_uint(q0.x), 0x0C0C0400u);
+              const uint32_t b0 = __builtin_amdgcn_perm(__float_as_uint(q0.w), __float_as_uint(q0.z), 0x0C0C0400u);
+              c0 = __builtin_amdgcn_perm(b0, a0, 0x05040100u);
+              const uint32_t a1 = __builtin_amdgcn_perm(__float_as_uint(q2.y), __float_as_uint(q2.x), 0x0C0C0400u);
+              const uint32_t b1 = __builtin_amdgcn_perm(__float_as_uint(q2.w), __float_as_uint(q2.z), 0x0C0C0400u);
+              c1 = __builtin_amdgcn_perm(b1, a1, 0x05040100u);
             } else {
               const float4 *n = (const float4 *)(nodes_base + (cur << 6));  // 32-bit offset: < 4 GiB of nodes
               q0 = n[0]; q1 = n[1]; q2 = n[2]; q3 = n[3];
+              c0 = __float_as_uint(q3.x); c1 = __float_as_uint(q3.y);
+#ifdef RTGPU_EXP_EXTRA_LOADS  // experiment: what does one more wave-level load per node step cost?
+              {
+                const float4 *n2 = (const float4 *)(nodes_base + (cur << 6) + (P.sample_offset << 6));  // same node (offset 0 at run time)
+#pragma unroll
+                for (int k = 0; k < RTGPU_EXP_EXTRA_LOADS; k++) exp_dummy += n2[k & 3].x;
+              }
+#endif
             }
             if (STATS) n_nodes++;
             // child 0: lo (q0.x q0.y q0.z) hi (q0.w q1.x q1.y); child 1: lo (q1.z q1.w q2.x) hi (q2.y q2.z q2.w)
@@ -689,7 +722,6 @@ void trace_kernel(const KParams P) {
             float tf0 = fmin_(fmin_(fmax_(a0x, a1x), fmax_(a0y, a1y)), vmin_(fmax_(a0z, a1z), tbest));
             float tn1 = fmax_(fmax_(fmin_(b0x, b1x), fmin_(b0y, b1y)), vmax_(fmin_(b0z, b1z), tmin));
             float tf1 = fmin_(fmin_(fmax_(b0x, b1x), fmax_(b0y, b1y)), vmin_(fmax_(b0z, b1z), tbest));
-            uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
             // an empty child (scenes of < 2 primitives) has its box at +inf and can
             // never pass: tfar <= tbest <= FLT_MAX < tnear
             bool h0 = tn0 <= tf0;
@@ -762,6 +794,9 @@ void trace_kernel(const KParams P) {
   }
 #undef SECTION_END
 
+#ifdef RTGPU_EXP_EXTRA_LOADS
+  if (exp_dummy == 1.2345f) n_paths++;  // keeps the extra loads alive
+#endif
   // ---- counters: one atomic per wave and counter --------------------------------
   n_paths = wave_sum(n_paths);
   n_rays = wave_sum(n_rays);
@@ -898,6 +933,7 @@ struct rtgpu_ctx {
   mutable bool host_stale = false;  // rtgpu_refit changed the device arrays; host copy refreshed on demand
   void *d_nodes = nullptr, *d_tris = nullptr, *d_sphs = nullptr, *d_sph_meta = nullptr,
        *d_mats = nullptr;
+  void *d_nodes48 = nullptr;    // packed nodes of a tree of >= RTGPU_NODE48_MIN_NODES nodes, else NULL
   unsigned long long *d_counters = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
@@ -929,11 +965,11 @@ namespace {
 // code path; the threshold only changes WHEN finished lanes are refilled, never
 // what a path computes.  RTGPU_REFILL (0/16/32) selects it for experiments.
 using KernelFn = void (*)(const KParams);
-struct Variant { int refill; KernelFn fn[3][3]; };  // [plain, stats, profile][MODE 0, 1, 2 of trace_kernel]
-#define RTGPU_VARIANT(R)                                                                   \
-  {R, {{trace_kernel<0, R, 0>, trace_kernel<0, R, 1>, trace_kernel<0, R, 2>},               \
-       {trace_kernel<1, R, 0>, trace_kernel<1, R, 1>, trace_kernel<1, R, 2>},               \
-       {trace_kernel<2, R, 0>, trace_kernel<2, R, 1>, trace_kernel<2, R, 2>}}}
+constexpr int kModes = 5;
+struct Variant { int refill; KernelFn fn[3][kModes]; };  // [plain, stats, profile][MODE 0..4 of trace_kernel]
+#define RTGPU_VARIANT_ROW(S, R) \
+  {trace_kernel<S, R, 0>, trace_kernel<S, R, 1>, trace_kernel<S, R, 2>, trace_kernel<S, R, 3>, trace_kernel<S, R, 4>}
+#define RTGPU_VARIANT(R) {R, {RTGPU_VARIANT_ROW(0, R), RTGPU_VARIANT_ROW(1, R), RTGPU_VARIANT_ROW(2, R)}}
 const Variant kVariants[] = {RTGPU_VARIANT(0), RTGPU_VARIANT(16), RTGPU_VARIANT(32)};
 // Default refill threshold, by what bounds the scene: 16 where the whole tree
 // sits in LDS and the kernel is VALU-bound (an outer iteration is expensive, so leave
@@ -953,8 +989,8 @@ bool hip_fail(rtgpu_ctx *ctx, hipError_t e, const char *what) {
 
 void free_scene_device(rtgpu_ctx *ctx) {
   (void)hipFree(ctx->d_nodes);  (void)hipFree(ctx->d_tris);  (void)hipFree(ctx->d_sphs);
-  (void)hipFree(ctx->d_sph_meta);  (void)hipFree(ctx->d_mats);
-  ctx->d_nodes = ctx->d_tris = ctx->d_sphs = ctx->d_sph_meta = ctx->d_mats = nullptr;
+  (void)hipFree(ctx->d_sph_meta);  (void)hipFree(ctx->d_mats);  (void)hipFree(ctx->d_nodes48);
+  ctx->d_nodes = ctx->d_tris = ctx->d_sphs = ctx->d_sph_meta = ctx->d_mats = ctx->d_nodes48 = nullptr;
   rtgpu::free_flat_scene(&ctx->host);
   ctx->have_scene = false;
   ctx->host_stale = false;
@@ -1039,7 +1075,7 @@ extern "C" int rtgpu_create(rtgpu_ctx **out, int device_index) {
   // one 1024-thread block per CU, holding all 160 KiB of its LDS
   for (const Variant &v : kVariants)
     for (int a = 0; a < 3; a++)
-      for (int b = 0; b < 3; b++)
+      for (int b = 0; b < kModes; b++)
         if ((e = hipFuncSetAttribute((const void *)v.fn[a][b], hipFuncAttributeMaxDynamicSharedMemorySize,
                                      kLdsBytes)) != hipSuccess) {
           rtgpu::set_global_error(std::string("rtgpu_create: LDS attribute: ") + hipGetErrorString(e));
@@ -1094,7 +1130,8 @@ extern "C" int rtgpu_upload_scene(rtgpu_ctx *ctx, const rtgpu_scene_desc *scene)
       upload(ctx, &ctx->d_tris, h.tris, (h.n_tris + 8) * sizeof(rtgpu_tri)) ||
       upload(ctx, &ctx->d_sphs, h.spheres, (h.n_spheres + 8) * sizeof(rtgpu_sph)) ||
       upload(ctx, &ctx->d_sph_meta, h.sphere_meta, (h.n_spheres * 2 + 16) * sizeof(uint32_t)) ||
-      upload(ctx, &ctx->d_mats, h.materials, h.n_materials * sizeof(rtgpu_material))) {
+      upload(ctx, &ctx->d_mats, h.materials, h.n_materials * sizeof(rtgpu_material)) ||
+      (h.nodes48 && upload(ctx, &ctx->d_nodes48, h.nodes48, h.n_nodes * sizeof(rtgpu_node48)))) {
     std::string keep = ctx->err;
     free_scene_device(ctx);
     ctx->err = keep;
@@ -1129,7 +1166,24 @@ extern "C" int rtgpu_upload_scene_lbvh(rtgpu_ctx *ctx, const rtgpu_scene_desc *s
   h.nodes = hn; h.tris = ht; h.spheres = hs; h.sphere_meta = (const uint32_t *)hm;
   h.materials = rtgpu::flatten_materials(scene);
   hipError_t e = hipSuccess;
-  if (!hn || !ht || !hs || !hm || !h.materials) {
+  void *h48 = nullptr;
+  const size_t pb = (size_t)h.n_nodes * sizeof(rtgpu_node48);
+  if (h.n_nodes >= RTGPU_NODE48_MIN_NODES) {
+    h48 = std::aligned_alloc(64, (pb + 63) / 64 * 64);
+    h.nodes48 = h48;
+    if ((e = hipMalloc(&ctx->d_nodes48, (pb + 63) / 64 * 64)) != hipSuccess) {
+      ctx->err = std::string("lbvh: packed nodes: ") + hipGetErrorString(e);
+      free_scene_device(ctx);
+      return 2;
+    }
+    std::string perr;
+    if (int prc = rtgpu::pack_nodes48_device(ctx->d_nodes, h.n_nodes, ctx->d_nodes48, perr)) {
+      free_scene_device(ctx);
+      ctx->err = perr;
+      return prc;
+    }
+  }
+  if (!hn || !ht || !hs || !hm || !h.materials || (h.n_nodes >= RTGPU_NODE48_MIN_NODES && !h48)) {
     ctx->err = "out of host memory for the flattened scene";
     free_scene_device(ctx);
     return 2;
@@ -1138,6 +1192,7 @@ extern "C" int rtgpu_upload_scene_lbvh(rtgpu_ctx *ctx, const rtgpu_scene_desc *s
       (e = hipMemcpy(ht, ctx->d_tris, tb, hipMemcpyDeviceToHost)) != hipSuccess ||
       (e = hipMemcpy(hs, ctx->d_sphs, sb, hipMemcpyDeviceToHost)) != hipSuccess ||
       (e = hipMemcpy(hm, ctx->d_sph_meta, mb, hipMemcpyDeviceToHost)) != hipSuccess ||
+      (h48 && (e = hipMemcpy(h48, ctx->d_nodes48, pb, hipMemcpyDeviceToHost)) != hipSuccess) ||
       upload(ctx, &ctx->d_mats, h.materials, h.n_materials * sizeof(rtgpu_material))) {
     std::string keep = e != hipSuccess ? std::string("lbvh: copy back: ") + hipGetErrorString(e) : ctx->err;
     free_scene_device(ctx);
@@ -1172,6 +1227,7 @@ extern "C" int rtgpu_refit(rtgpu_ctx *ctx, const rtgpu_scene_desc *scene) {
   ctx->host_stale = true;
   double ms = 0.0;
   int rc = rtgpu::refit_device(scene, ctx->d_nodes, h.n_nodes, ctx->d_tris, ctx->d_sphs, ctx->d_sph_meta, &ms, ctx->err);
+  if (!rc && ctx->d_nodes48) rc = rtgpu::pack_nodes48_device(ctx->d_nodes, h.n_nodes, ctx->d_nodes48, ctx->err);
   if (rc) {  // the device arrays may be half rewritten: the scene is gone
     std::string keep = ctx->err;
     free_scene_device(ctx);
@@ -1190,7 +1246,8 @@ extern "C" int rtgpu_get_flat_scene(const rtgpu_ctx *ctx, rtgpu_flat_scene *out)
         hipMemcpy((void *)h.nodes, ctx->d_nodes, (size_t)h.n_nodes * sizeof(rtgpu_node), hipMemcpyDeviceToHost) != hipSuccess ||
         hipMemcpy((void *)h.tris, ctx->d_tris, (size_t)h.n_tris * sizeof(rtgpu_tri), hipMemcpyDeviceToHost) != hipSuccess ||
         hipMemcpy((void *)h.spheres, ctx->d_sphs, (size_t)h.n_spheres * sizeof(rtgpu_sph), hipMemcpyDeviceToHost) != hipSuccess ||
-        hipMemcpy((void *)h.sphere_meta, ctx->d_sph_meta, (size_t)h.n_spheres * 2 * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess)
+        hipMemcpy((void *)h.sphere_meta, ctx->d_sph_meta, (size_t)h.n_spheres * 2 * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess ||
+        (h.nodes48 && hipMemcpy((void *)h.nodes48, ctx->d_nodes48, (size_t)h.n_nodes * sizeof(rtgpu_node48), hipMemcpyDeviceToHost) != hipSuccess))
       return 2;
     ctx->host_stale = false;
   }
@@ -1231,7 +1288,7 @@ extern "C" int rtgpu_render_device(rtgpu_ctx *ctx, const rtgpu_camera *cam, cons
 
   KParams P;
   std::memset(&P, 0, sizeof(P));
-  P.nodes = (const float4 *)ctx->d_nodes;
+  P.nodes = (const float4 *)(ctx->d_nodes48 ? ctx->d_nodes48 : ctx->d_nodes);  // packed nodes when the tree has them
   P.tris = (const float4 *)ctx->d_tris;
   P.sphs = (const float4 *)ctx->d_sphs;
   P.sph_meta = (const uint2 *)ctx->d_sph_meta;
@@ -1283,6 +1340,10 @@ extern "C" int rtgpu_render_device(rtgpu_ctx *ctx, const rtgpu_camera *cam, cons
     P.n_cached = (uint32_t)ctx->host.n_nodes;
     lds_bytes = stack_bytes + (size_t)kSmallNodes * sizeof(rtgpu_node);
   }
+  if (ctx->d_nodes48) {  // never a MODE 2 tree: RTGPU_NODE48_MIN_NODES > kSmallNodes
+    if (mode == 2) { ctx->err = "internal: packed nodes on a tree that fits the LDS cache"; return 2; }
+    mode += 3;
+  }
 
   bool want_stats = (s->flags & (RTGPU_FLAG_STATS | RTGPU_FLAG_PROFILE)) != 0;
   HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 256, stream));
@@ -1293,6 +1354,7 @@ extern "C" int rtgpu_render_device(rtgpu_ctx *ctx, const rtgpu_camera *cam, cons
     unsigned grid = (unsigned)(want < cap ? want : cap);
     if ((size_t)grid * kBlock > ctx->ovf_threads) { ctx->err = "internal: grid exceeds the overflow stack"; return 2; }
     const Variant &var = kVariants[ctx->variant >= 0 ? ctx->variant : (mode == 2 ? kVariantSmallTree : kVariantLargeTree)];
+    static_assert(RTGPU_NODE48_MIN_NODES > (unsigned)kSmallNodes, "a packed tree must not fit the LDS node cache");
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
     KernelFn fn = var.fn[(s->flags & RTGPU_FLAG_PROFILE) ? 2 : want_stats ? 1 : 0][mode];
     hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), lds_bytes, stream, P);

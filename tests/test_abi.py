@@ -23,13 +23,13 @@ def test_every_declared_symbol_is_exported(ra):
 
 
 def test_abi_version_and_struct_sizes(ra):
-    assert ra.lib.rtgpu_abi_version() == 2
+    assert ra.lib.rtgpu_abi_version() == 3
     from rt_amd import api
     assert C.sizeof(api.Camera) == 80
     assert C.sizeof(api.Settings) == 72
     assert C.sizeof(api.Stats) == 48
     assert C.sizeof(api.SceneDesc) == 48
-    assert C.sizeof(api.FlatSceneC) == 88
+    assert C.sizeof(api.FlatSceneC) == 96
     assert api.MATERIAL_DTYPE.itemsize == 32 and api.SPHERE_DTYPE.itemsize == 20
     assert api.TRIANGLE_DTYPE.itemsize == 40
 

@@ -22,6 +22,7 @@ def _flat_bytes(c):
         "spheres": grab(c.spheres, (c.n_spheres + 8) * 16),
         "meta": grab(c.sphere_meta, (c.n_spheres * 2 + 16) * 4),
         "materials": grab(c.materials, c.n_materials * 32),
+        "nodes48": grab(c.nodes48, c.n_nodes * 48) if c.nodes48 else b"",
     }
 
 
