@@ -43,9 +43,6 @@ typedef struct rtgpu_node {
  * threshold. */
 typedef struct rtgpu_node48 {
   uint32_t w[12];
-#ifdef RTGPU_EXP_NODE48_STRIDE64  /* experiment only: packed words in 64-byte slots */
-  uint32_t exp_pad[4];
-#endif
 } rtgpu_node48;
 #define RTGPU_NODE48_MIN_NODES 1366u
 

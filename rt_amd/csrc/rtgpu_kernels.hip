@@ -285,7 +285,7 @@ __device__ __forceinline__ void wave_tick(unsigned lane, unsigned long long &c) 
 // four planes a compile-time distance apart, so a node fetch is one address and four
 // ds_read with immediate offsets, and no "cached or not" test.  3 and 4: as 0 and 1 with
 // the packed 48-byte nodes (rtgpu_format.h): three loads per node step instead of four -
-// on these trees the texture path is the bound and it is paid per load instruction.
+// every node fetch of such a tree goes to memory, and the packed form is a quarter smaller.
 template <int STATS, int REFILL, int MODE>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RTGPU_WAVES_PER_EU, RTGPU_WAVES_PER_EU)))
 void trace_kernel(const KParams P) {
@@ -364,9 +364,6 @@ void trace_kernel(const KParams P) {
 #define SECTION_END(acc) do { if (STATS == 2) { long long t_ = (long long)clock64(); acc += t_ - c_mark; c_mark = t_; } } while (0)
   if (STATS == 2) c_mark = (long long)clock64();
 
-#ifdef RTGPU_EXP_EXTRA_LOADS
-  float exp_dummy = 0.f;
-#endif
   for (;;) {
     // ---- (1) shade the rays whose traversal has finished (rows a6, a8) ----------
     if (STATS == 2) wave_tick(lane, w_outer);
@@ -394,7 +391,7 @@ void trace_kernel(const KParams P) {
           prim = meta.x;
           mat = meta.y;
         } else {
-          const float4 *tp = P.tris + (size_t)hit_slot * 3u;
+          const float4 *tp = P.tris + (size_t)hit_slot * (sizeof(rtgpu_tri) / 16);
           float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
           n = normalize(cross(mk(t1.x, t1.y, t1.z), mk(t2.x, t2.y, t2.z)));
           prim = __float_as_uint(t0.w);
@@ -677,11 +674,7 @@ void trace_kernel(const KParams P) {
               // bytes of q0's and q2's four planes, gathered with three v_perm_b32 each
               uint32_t c3;
               asm("v_lshl_add_u32 %0, %1, 1, %1" : "=v"(c3) : "v"(cur));
-#ifdef RTGPU_EXP_NODE48_STRIDE64
-              const float4 *n = (const float4 *)(nodes_base + (cur << 6));
-#else
               const float4 *n = (const float4 *)(nodes_base + (c3 << 4));
-#endif
               q0 = n[0]; q1 = n[1]; q2 = n[2];
               q3 = q2;
               const uint32_t a0 = __builtin_amdgcn_perm(__float_as_uint(q0.y), __float_as_uint(q0.x), 0x0C0C0400u);
@@ -694,13 +687,6 @@ void trace_kernel(const KParams P) {
               const float4 *n = (const float4 *)(nodes_base + (cur << 6));  // 32-bit offset: < 4 GiB of nodes
               q0 = n[0]; q1 = n[1]; q2 = n[2]; q3 = n[3];
               c0 = __float_as_uint(q3.x); c1 = __float_as_uint(q3.y);
-#ifdef RTGPU_EXP_EXTRA_LOADS  // experiment: what does one more wave-level load per node step cost?
-              {
-                const float4 *n2 = (const float4 *)(nodes_base + (cur << 6) + (P.sample_offset << 6));  // same node (offset 0 at run time)
-#pragma unroll
-                for (int k = 0; k < RTGPU_EXP_EXTRA_LOADS; k++) exp_dummy += n2[k & 3].x;
-              }
-#endif
             }
             if (STATS) n_nodes++;
             // child 0: lo (q0.x q0.y q0.z) hi (q0.w q1.x q1.y); child 1: lo (q1.z q1.w q2.x) hi (q2.y q2.z q2.w)
@@ -794,9 +780,6 @@ void trace_kernel(const KParams P) {
   }
 #undef SECTION_END
 
-#ifdef RTGPU_EXP_EXTRA_LOADS
-  if (exp_dummy == 1.2345f) n_paths++;  // keeps the extra loads alive
-#endif
   // ---- counters: one atomic per wave and counter --------------------------------
   n_paths = wave_sum(n_paths);
   n_rays = wave_sum(n_rays);
@@ -973,8 +956,8 @@ struct Variant { int refill; KernelFn fn[3][kModes]; };  // [plain, stats, profi
 const Variant kVariants[] = {RTGPU_VARIANT(0), RTGPU_VARIANT(16), RTGPU_VARIANT(32)};
 // Default refill threshold, by what bounds the scene: 16 where the whole tree
 // sits in LDS and the kernel is VALU-bound (an outer iteration is expensive, so leave
-// the traversal loop late); 32 where nodes come through the texture path, whose cost is
-// per load INSTRUCTION however few lanes take part (so keep traversal steps full).
+// the traversal loop late); 32 where nodes come from memory and the time follows the
+// number of dependent steps a ray takes (so keep the lanes of a step together).
 constexpr int kVariantSmallTree = 1, kVariantLargeTree = 2;
 
 bool hip_fail(rtgpu_ctx *ctx, hipError_t e, const char *what) {
