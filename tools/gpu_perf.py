@@ -16,6 +16,7 @@ CONFIGS = {
     "c5full": (2, 8, 1920, 1080, 4, 8),
     "c3full": (1, 8, 1920, 1080, 64, 8),   # C3 as BASELINE.json states it
     "c4": (0, 0, 3840, 2160, 256, 8),      # C4's frame on ONE GPU (its 2/4/8-GPU runs are the driver's)
+    "c2lens": (0, 0, 1920, 1080, 16, 8, 0.1),  # C2 through the thin lens (aperture 0.1)
 }
 
 def main():
@@ -28,9 +29,11 @@ def main():
     names = [a for a in args if not a.startswith("--")] or ["c2", "c3", "c5"]
     ctx = ra.Context(0)
     for name in names:
-        kind, level, w, h, spp, depth = CONFIGS[name]
+        kind, level, w, h, spp, depth = CONFIGS[name][:6]
         t0 = time.time()
         scene, cam = ra.Scene.builtin(kind, param=level, aspect=w / h)
+        if len(CONFIGS[name]) > 6:  # the RTIOW cover camera with an aperture
+            cam = ra.look_at((13, 2, 3), (0, 0, 0), vfov=20.0, aspect=w / h, aperture=CONFIGS[name][6], focus_dist=10.0)
         t1 = time.time()
         ctx.upload(scene, builder=os.environ.get("RT_BUILDER", "sah"))
         t2 = time.time()
