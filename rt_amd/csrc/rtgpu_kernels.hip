@@ -64,7 +64,7 @@ struct KParams {
   float4       *accum;
   uint32_t     *prim_id;
   uint32_t     *ovf_stack;  // [kStackOvf][grid threads], see struct Stack
-  unsigned long long *wave_times;  // profile variant: {start, end, queue-dry} s_memrealtime per wave (100 MHz)
+  unsigned long long *wave_times;  // profile variant, per wave: {start, end, queue-dry} s_memrealtime (100 MHz), outer iterations after dry
   unsigned long long *counters;  // [0] queue head, [1] paths, [2] rays, [3] nodes, [4] tris, [5] sphs, [6] scatters, [7..20] profile
   float cam_origin[3], cam_ll[3], cam_hor[3], cam_ver[3], cam_u[3], cam_v[3];
   float lens_radius;
@@ -364,9 +364,10 @@ void trace_kernel(const KParams P) {
 #define SECTION_END(acc) do { if (STATS == 2) { long long t_ = (long long)clock64(); acc += t_ - c_mark; c_mark = t_; } } while (0)
   if (STATS == 2) c_mark = (long long)clock64();
 
+  unsigned long long n_after_dry = 0;
   for (;;) {
     // ---- (1) shade the rays whose traversal has finished (rows a6, a8) ----------
-    if (STATS == 2) wave_tick(lane, w_outer);
+    if (STATS == 2) { wave_tick(lane, w_outer); if (queue_dry) n_after_dry++; }
     if (alive && cur == kDone) {
       if (STATS == 2) { wave_tick(lane, w_shade); l_shade++; }
       V3 L = mk(0.f, 0.f, 0.f);
@@ -803,9 +804,10 @@ void trace_kernel(const KParams P) {
     unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
     if (lane == 0) {
       size_t w = ((size_t)blockIdx.x * kBlock + tid) >> 6;
-      P.wave_times[w * 3 + 0] = t_start;
-      P.wave_times[w * 3 + 1] = t_end;
-      P.wave_times[w * 3 + 2] = t_dry;
+      P.wave_times[w * 4 + 0] = t_start;
+      P.wave_times[w * 4 + 1] = t_end;
+      P.wave_times[w * 4 + 2] = t_dry;
+      P.wave_times[w * 4 + 3] = n_after_dry;
     }
     unsigned long long v[9] = {w_outer, w_shade, l_shade, w_gen, w_node, w_sph, w_tri, w_trav, l_trav};
 #pragma unroll
@@ -926,7 +928,7 @@ struct rtgpu_ctx {
   bool no_node_cache = false;   // RTGPU_NO_NODE_CACHE=1: every node through the vector L1 (experiments)
   int blocks_per_cu[2] = {0, 0};
   uint32_t *d_ovf = nullptr;    // traversal-stack overflow, sized for the largest grid
-  unsigned long long *d_wave_times = nullptr;  // profile variant: 3 x u64 per wave
+  unsigned long long *d_wave_times = nullptr;  // profile variant: 4 x u64 per wave
   float4 *d_planes = nullptr;   // chunk planes (grow-only, zero-filled when (re)allocated)
   size_t planes_bytes = 0;
   size_t ovf_threads = 0;
@@ -1067,7 +1069,7 @@ extern "C" int rtgpu_create(rtgpu_ctx **out, int device_index) {
         }
   ctx->blocks_per_cu[0] = ctx->blocks_per_cu[1] = kBlocksPerCU;
   ctx->ovf_threads = (size_t)ctx->num_cus * kBlocksPerCU * kBlock;
-  if ((e = hipMalloc((void **)&ctx->d_wave_times, (size_t)ctx->num_cus * kBlocksPerCU * (kBlock / 64) * 3 * 8)) != hipSuccess) {
+  if ((e = hipMalloc((void **)&ctx->d_wave_times, (size_t)ctx->num_cus * kBlocksPerCU * (kBlock / 64) * 4 * 8)) != hipSuccess) {
     rtgpu::set_global_error(std::string("rtgpu_create: ") + hipGetErrorString(e));
     rtgpu_destroy(ctx);
     return 2;
@@ -1420,15 +1422,16 @@ extern "C" int rtgpu_debug_occupancy(rtgpu_ctx *ctx, uint64_t lds_bytes, int *bl
   return 0;
 }
 
-// Diagnostics (not in the public header): {start, end, queue-dry} 100 MHz
-// timestamps of every wave of the last RTGPU_FLAG_PROFILE launch.
+// Diagnostics (not in the public header): {start, end, queue-dry} 100 MHz timestamps and
+// the outer iterations after queue-dry of every wave of the last RTGPU_FLAG_PROFILE launch
+// (4 u64 per wave).
 extern "C" int rtgpu_debug_wave_times(rtgpu_ctx *ctx, uint64_t *out, uint64_t max_waves, uint64_t *n_waves) {
   if (!ctx || !out || !n_waves) return 1;
   uint64_t n = (uint64_t)ctx->num_cus * kBlocksPerCU * (kBlock / 64);
   if (n > max_waves) n = max_waves;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipDeviceSynchronize());
-  HIP_TRY(ctx, hipMemcpy(out, ctx->d_wave_times, n * 3 * 8, hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpy(out, ctx->d_wave_times, n * 4 * 8, hipMemcpyDeviceToHost));
   *n_waves = n;
   return 0;
 }

@@ -7,13 +7,14 @@ from gpu_perf import CONFIGS
 ctx = ra.Context(0)
 ra.lib.rtgpu_debug_wave_times.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
 for name in sys.argv[1:] or ["c2"]:
-    kind, level, w, h, spp, depth = CONFIGS[name]
+    kind, level, w, h, spp, depth = CONFIGS[name][:6]
+    depth = int(os.environ.get("RT_DEPTH", depth))
     scene, cam = ra.Scene.builtin(kind, param=level, aspect=w / h)
     ctx.upload(scene)
     acc = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
     st = ra.default_settings(w, h, spp=spp, max_depth=depth, flags=ra.FLAG_PROFILE)
     ctx.render_device(cam, st, acc.data_ptr(), None, None)
-    buf = np.zeros((8192, 3), np.uint64); n = C.c_uint64()
+    buf = np.zeros((8192, 4), np.uint64); n = C.c_uint64()
     assert ra.lib.rtgpu_debug_wave_times(ctx._h, buf.ctypes.data, 8192, C.byref(n)) == 0
     t = buf[: n.value].astype(np.float64)
     t0 = t[:, 0].min()
@@ -24,5 +25,6 @@ for name in sys.argv[1:] or ["c2"]:
     print("   queue dry", q(dry[dry > 0]))
     print("   end      ", q(end))
     print("   end - dry", q((end - dry)[dry > 0]))
+    print("   outer iterations after dry", q(t[:, 3][dry > 0]), " -> us per iteration", f"{np.median(((end - dry) / np.maximum(t[:, 3], 1))[dry > 0]):.1f}")
     print(f"   mean busy share until last end: {(end - start).sum() / (len(end) * end.max()):.3f}")
 ctx.close()
