@@ -201,7 +201,7 @@ def main():
     if rank == 0:
         k_ms = sum(kernel_ms) / len(kernel_ms)
         n_px_rank = counts["paths"] // spp
-        abytes = algorithmic_bytes(counts, n_px_rank, 48 if ctx.flat_scene().c.nodes48 else 64)
+        abytes = algorithmic_bytes(counts, n_px_rank, (96 if ctx.flat_scene().c.nodes4 else 48 if ctx.flat_scene().c.nodes48 else 64))
         aflops = algorithmic_flops(counts)
         achieved = abytes / (k_ms * 1e-3) / 1e9
         traffic, traffic_src, pmc = measured_traffic(W, H, args.spp, depth, world)

@@ -151,7 +151,13 @@ typedef struct rtgpu_flat_scene {
   double         build_ms;
   const void    *nodes48;      /* n_nodes packed nodes of 48 B (rtgpu_format.h) when
                                   n_nodes >= RTGPU_NODE48_MIN_NODES, else NULL: the
-                                  array the trace loop traverses when present     */
+                                  array the trace loop traverses when nodes4 is
+                                  absent (after a refit)                          */
+  const void    *nodes4;       /* n_nodes4 four-wide packed nodes of 96 B, same
+                                  threshold; traversed in preference when present  */
+  uint64_t       n_nodes4;
+  uint32_t       max_stack4;   /* bound on the traversal stack over nodes4         */
+  uint32_t       _pad2;
 } rtgpu_flat_scene;
 
 typedef struct rtgpu_ctx rtgpu_ctx;

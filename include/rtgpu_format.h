@@ -46,6 +46,27 @@ typedef struct rtgpu_node48 {
 } rtgpu_node48;
 #define RTGPU_NODE48_MIN_NODES 1366u
 
+/* Four-wide packed node, 96 bytes, 16-byte aligned: up to four children per node,
+ * made by collapsing the BVH2 (a node absorbs the inner child of largest surface
+ * area until it has four children or only leaves; child order = BVH2 order).  On
+ * trees too large for LDS the time of a ray follows the number of DEPENDENT node
+ * fetches it makes; a four-wide tree roughly halves that number.
+ * Child k (0..3) owns words 6k .. 6k+5 = lo.x lo.y lo.z hi.x hi.y hi.z; byte j of
+ * its reference is the low byte of word 6k + j, and those four planes sit on the
+ * conservative side of the exact ones exactly as in rtgpu_node48 (lo planes moved
+ * down, hi.x up, < 256 floats); hi.y and hi.z are exact.  A missing child has the
+ * reference RTGPU_REF_EMPTY and a box collapsed at RTGPU_NODE4_FAR on every axis,
+ * which no ray reaches.  Present from RTGPU_NODE48_MIN_NODES BVH2 nodes up, and
+ * then the array the trace loop and the oracle traverse (a refit drops it: the
+ * loop falls back to the packed BVH2 until the next upload).
+ * Traversal order at a node: children whose slab test passes, by ascending key
+ * ((bits of tnear) & 0x7FFFFFFC) | k - nearest first, the others pushed farthest
+ * first. */
+typedef struct rtgpu_node4 {
+  uint32_t w[24];
+} rtgpu_node4;
+#define RTGPU_NODE4_FAR 0x7F000000u /* 2^127 as float bits */
+
 /* Child reference (also the traversal-stack entry):
  *   bit 31 = 0 : inner node, bits 0..30 = node index
  *   bit 31 = 1 : leaf; bit 30 = 1 sphere / 0 triangle;

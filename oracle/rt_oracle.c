@@ -225,6 +225,7 @@ RTO_API int rto_kat_tri(const float *o, const float *d, const float *v0, const f
 typedef struct {
   const rtgpu_node *nodes;
   const rtgpu_node48 *nodes48; /* packed form (rtgpu_format.h); traversed instead of nodes when present */
+  const rtgpu_node4 *nodes4;   /* four-wide packed form; traversed in preference when present */
   const rtgpu_tri *tris;
   const rtgpu_sph *sphs;
   const uint32_t *sph_meta;
@@ -277,7 +278,60 @@ RTO_API int rto_debug_max_stack(int reset) {
   return v;
 }
 
+/* Closest hit over the four-wide packed nodes (rtgpu_node4, include/rtgpu_format.h):
+ * one node fetch tests up to four children; those that pass are visited by ascending
+ * key ((bits of tnear) & 0x7FFFFFFC) | k - the nearest now, the others pushed farthest
+ * first; a popped entry is visited without any re-test.  The planes are the words as
+ * stored (sixteen of the twenty-four carry a byte of a child reference in their low
+ * byte and were moved to the conservative side by the builder). */
+static hit_t intersect_bvh4(const scene_t *sc, const ray_t *r, float tmin, counters_t *cn) {
+  hit_t best = {0, 0, 0, T_MAX};
+  uint32_t stack[3 * (RTGPU_MAX_TREE_DEPTH + 2) + 2];
+  int sp = 0;
+  uint32_t cur = 0; /* root */
+  for (;;) {
+    if (cur & RTGPU_REF_LEAF) {
+      if (cur != RTGPU_REF_EMPTY) leaf_intersect(sc, r, cur, tmin, &best, cn);
+    } else {
+      const uint32_t *w = sc->nodes4[cur].w;
+      float pl[24];
+      memcpy(pl, w, sizeof(pl));
+      cn->nodes++;
+      uint32_t key[4], ref[4];
+      int n = 0;
+      for (int k = 0; k < 4; k++) {
+        float tn;
+        const uint32_t *cw = w + 6 * k;
+        ref[k] = (cw[0] & 0xFFu) | ((cw[1] & 0xFFu) << 8) | ((cw[2] & 0xFFu) << 16) | ((cw[3] & 0xFFu) << 24);
+        int h = slab(r, pl + 6 * k, pl + 6 * k + 3, tmin, best.t, &tn);
+        uint32_t tb;
+        memcpy(&tb, &tn, 4);
+        key[k] = h ? ((tb & 0x7FFFFFFCu) | (uint32_t)k) : 0xFFFFFFFFu;
+        n += h;
+      }
+      if (n > 0) {
+        /* ascending keys (distinct among the hits); misses (all ones) sort last */
+        uint32_t ord[4] = {key[0], key[1], key[2], key[3]};
+        for (int a = 1; a < 4; a++) {
+          uint32_t v = ord[a];
+          int b = a - 1;
+          while (b >= 0 && ord[b] > v) { ord[b + 1] = ord[b]; b--; }
+          ord[b + 1] = v;
+        }
+        for (int a = n - 1; a >= 1; a--) stack[sp++] = ref[ord[a] & 3u];
+        if (sp > g_max_stack) g_max_stack = sp;
+        cur = ref[ord[0] & 3u];
+        continue;
+      }
+    }
+    if (sp == 0) break;
+    cur = stack[--sp];
+  }
+  return best;
+}
+
 static hit_t intersect_bvh(const scene_t *sc, const ray_t *r, float tmin, counters_t *cn) {
+  if (sc->nodes4) return intersect_bvh4(sc, r, tmin, cn);
   hit_t best = {0, 0, 0, T_MAX};
   uint32_t stack[RTGPU_MAX_TREE_DEPTH + 2];
   int sp = 0;
@@ -543,6 +597,7 @@ RTO_API int rto_render(const rtgpu_flat_scene *fs, const rtgpu_camera *cam, cons
   scene_t sc;
   sc.nodes = (const rtgpu_node *)fs->nodes;
   sc.nodes48 = (const rtgpu_node48 *)fs->nodes48;
+  sc.nodes4 = (const rtgpu_node4 *)fs->nodes4;
   sc.tris = (const rtgpu_tri *)fs->tris;
   sc.sphs = (const rtgpu_sph *)fs->spheres;
   sc.sph_meta = fs->sphere_meta;
@@ -649,6 +704,21 @@ static int box_inside(const float *lo, const float *hi, const float *plo, const 
   return 1;
 }
 
+/* a child box of a packed node may stick out of the box its parent stores for that
+ * node by the packing move (each plane is moved on its own, < 512 floats) */
+static int64_t ord_f32(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  return (u & 0x80000000u) ? -(int64_t)(u & 0x7FFFFFFFu) - 1 : (int64_t)u;
+}
+static int box_inside_packed(const float *lo, const float *hi, const float *plo, const float *phi) {
+  for (int k = 0; k < 3; k++) {
+    if (isinf(plo[k]) && isinf(phi[k])) continue; /* the root's "parent" */
+    if (ord_f32(lo[k]) < ord_f32(plo[k]) - 512 || ord_f32(hi[k]) > ord_f32(phi[k]) + 512) return 0;
+  }
+  return 1;
+}
+
 RTO_API int rto_validate_bvh(const rtgpu_flat_scene *fs, uint32_t *max_depth_out) {
   const rtgpu_node *nodes = (const rtgpu_node *)fs->nodes;
   const rtgpu_tri *tris = (const rtgpu_tri *)fs->tris;
@@ -727,6 +797,78 @@ RTO_API int rto_validate_bvh(const rtgpu_flat_scene *fs, uint32_t *max_depth_out
         if (!moved ? a != b : (is_lo ? (a > b || b - a > lim) : (a < b || a - b > lim))) { rc = 12; break; }
       }
     }
+  }
+  /* four-wide nodes: present from the same threshold; every node reached once from the
+   * root, every primitive referenced once, every child box inside the box its parent
+   * stores for that node, every primitive inside its leaf's box, stack bound honoured */
+  if (!rc && fs->nodes4 && fs->n_nodes < RTGPU_NODE48_MIN_NODES) rc = 13;
+  if (!rc && fs->nodes4) {
+    const rtgpu_node4 *n4 = (const rtgpu_node4 *)fs->nodes4;
+    memset(seen_t, 0, fs->n_tris + 1);
+    memset(seen_s, 0, fs->n_spheres + 1);
+    typedef struct { uint32_t ref; uint32_t on_stack; float lo[3], hi[3]; } item4_t;
+    size_t cap4 = 4 * (size_t)fs->n_nodes4 + 16, sp4 = 0;
+    item4_t *st4 = (item4_t *)malloc(cap4 * sizeof(item4_t));
+    uint64_t visited = 0;
+    item4_t root4 = {0, 0, {-INFINITY, -INFINITY, -INFINITY}, {INFINITY, INFINITY, INFINITY}};
+    st4[sp4++] = root4;
+    while (sp4 && !rc) {
+      item4_t it = st4[--sp4];
+      if (it.ref == RTGPU_REF_EMPTY) continue;
+      if (it.ref & RTGPU_REF_LEAF) {
+        uint32_t first = RTGPU_REF_FIRST(it.ref), count = RTGPU_REF_COUNT(it.ref);
+        for (uint32_t i = first; i < first + count && !rc; i++) {
+          float lo[3], hi[3];
+          if (it.ref & RTGPU_REF_SPHERE) {
+            if (i >= fs->n_spheres) { rc = 14; break; }
+            if (seen_s[i]++) { rc = 15; break; }
+            for (int k = 0; k < 3; k++) { lo[k] = sphs[i].c[k] - sphs[i].r; hi[k] = sphs[i].c[k] + sphs[i].r; }
+          } else {
+            if (i >= fs->n_tris) { rc = 14; break; }
+            if (seen_t[i]++) { rc = 15; break; }
+            for (int k = 0; k < 3; k++) {
+              float a = tris[i].v0[k], b = a + tris[i].e1[k], c = a + tris[i].e2[k];
+              lo[k] = fminf(a, fminf(b, c)); hi[k] = fmaxf(a, fmaxf(b, c));
+              float e = fmaxf(fmaxf(fabsf(lo[k]), fabsf(hi[k])), 1.0f) * 0x1p-22f;
+              lo[k] += e; hi[k] -= e;
+              if (lo[k] > hi[k]) lo[k] = hi[k] = 0.5f * (lo[k] + hi[k]);
+            }
+          }
+          if (!box_inside(lo, hi, it.lo, it.hi)) rc = 16;
+        }
+        continue;
+      }
+      if (it.ref >= fs->n_nodes4) { rc = 14; break; }
+      visited++;
+      const uint32_t *w = n4[it.ref].w;
+      int nch = 0;
+      for (int k = 0; k < 4; k++) {
+        const uint32_t *cw = w + 6 * k;
+        uint32_t ref = (cw[0] & 0xFFu) | ((cw[1] & 0xFFu) << 8) | ((cw[2] & 0xFFu) << 16) | ((cw[3] & 0xFFu) << 24);
+        if (ref == RTGPU_REF_EMPTY) continue;
+        nch++;
+        item4_t c;
+        c.ref = ref;
+        memcpy(c.lo, cw, 12);
+        memcpy(c.hi, cw + 3, 12);
+        if (!box_inside_packed(c.lo, c.hi, it.lo, it.hi)) { rc = 17; break; }
+        c.on_stack = 0;
+        if (sp4 + 1 > cap4) { rc = 18; break; }
+        st4[sp4++] = c;
+      }
+      if (!rc && nch < 2) rc = 19;
+      /* siblings that can lie below this node's descendants on the traversal stack */
+      for (size_t q = sp4 - (size_t)nch; !rc && q < sp4; q++) {
+        st4[q].on_stack = it.on_stack + (uint32_t)nch - 1u;
+        if (st4[q].on_stack > fs->max_stack4) rc = 20;
+      }
+    }
+    if (!rc && visited != fs->n_nodes4) rc = 21;
+    if (!rc) {
+      for (uint64_t i = 0; i < fs->n_tris; i++) if (seen_t[i] != 1) { rc = 22; break; }
+      for (uint64_t i = 0; i < fs->n_spheres; i++) if (seen_s[i] != 1) { rc = 22; break; }
+    }
+    free(st4);
   }
   if (max_depth_out) *max_depth_out = maxd;
   free(seen_t); free(seen_s); free(stack);
@@ -884,6 +1026,7 @@ RTO_API void rto_flat_free(rtgpu_flat_scene *fs) {
   if (!fs) return;
   free((void *)fs->nodes); free((void *)fs->tris); free((void *)fs->spheres);
   free((void *)fs->sphere_meta); free((void *)fs->materials); free((void *)fs->nodes48);
+  free((void *)fs->nodes4);
   memset(fs, 0, sizeof(*fs));
 }
 

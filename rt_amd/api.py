@@ -117,6 +117,8 @@ class FlatSceneC(C.Structure):
         ("max_depth", C.c_uint32), ("_pad", C.c_uint32),
         ("build_ms", C.c_double),
         ("nodes48", C.c_void_p),
+        ("nodes4", C.c_void_p), ("n_nodes4", C.c_uint64),
+        ("max_stack4", C.c_uint32), ("_pad2", C.c_uint32),
     ]
 
 
@@ -291,6 +293,13 @@ class FlatScene:
         if not self.c.nodes48:
             return np.zeros((0, 12), np.uint32)
         return self._view(self.c.nodes48, self.c.n_nodes, np.uint32, 12)
+
+    @property
+    def nodes4_u32(self):
+        """Four-wide packed nodes (24 words each); empty when absent."""
+        if not self.c.nodes4:
+            return np.zeros((0, 24), np.uint32)
+        return self._view(self.c.nodes4, self.c.n_nodes4, np.uint32, 24)
 
     @property
     def tris_f32(self):

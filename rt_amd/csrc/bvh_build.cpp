@@ -631,6 +631,8 @@ int flatten_scene(const rtgpu_scene_desc *scene, rtgpu_flat_scene *out, std::str
   if (out->n_nodes >= RTGPU_NODE48_MIN_NODES) {
     out->nodes48 = pack_nodes48((const rtgpu_node *)out->nodes, out->n_nodes, err);
     if (!out->nodes48) { free_flat_scene(out); return 1; }
+    out->nodes4 = collapse_nodes4((const rtgpu_node *)out->nodes, out->n_nodes, &out->n_nodes4, &out->max_stack4, err);
+    if (!out->nodes4) { free_flat_scene(out); return 1; }
   }
   out->build_ms =
       std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -645,6 +647,7 @@ void free_flat_scene(rtgpu_flat_scene *fs) {
   std::free((void *)fs->sphere_meta);
   std::free((void *)fs->materials);
   std::free((void *)fs->nodes48);
+  std::free((void *)fs->nodes4);
   std::memset(fs, 0, sizeof(*fs));
 }
 

@@ -18,6 +18,9 @@ int  validate_scene(const rtgpu_scene_desc *scene, std::string &err);
 rtgpu_material *flatten_materials(const rtgpu_scene_desc *scene);
 // 64-byte nodes -> packed 48-byte nodes (malloc'ed; NULL + err if a plane is not finite)
 rtgpu_node48 *pack_nodes48(const rtgpu_node *nodes, uint64_t n, std::string &err);
+// bvh4_build.cpp: 64-byte BVH2 nodes -> four-wide packed nodes (malloc'ed; NULL + err on failure)
+rtgpu_node4 *collapse_nodes4(const rtgpu_node *nodes, uint64_t n, uint64_t *n_out, uint32_t *max_stack,
+                             std::string &err);
 // pack48.hip: the same on the device (d_bad: one u32, set non-zero if a node has no packed form)
 int  pack_nodes48_device(const void *d_nodes, uint64_t n, void *d_nodes48, std::string &err);
 

@@ -244,6 +244,24 @@ struct Stack {
     if (none) { sp--; near_c = load(sp); }
     return near_c;
   }
+  // four-wide node step: n children hit, r0 the nearest, r1..r3 the others by distance;
+  // the others are pushed farthest first (the LDS form writes three entries whatever n is:
+  // what lies above the new top is never read)
+  __device__ __forceinline__ uint32_t step4(int n, uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3) {
+    if (LDS_ONLY) {
+      uint32_t top = top_at[0];
+      top_at[kBlock] = n == 4 ? r3 : (n == 3 ? r2 : r1);
+      top_at[2 * kBlock] = n == 4 ? r2 : r1;
+      top_at[3 * kBlock] = r1;
+      top_at += (n == 0 ? -1 : n - 1) * kBlock;
+      return n == 0 ? top : r0;
+    }
+    if (n == 0) { sp--; return load(sp); }
+    if (n >= 4) { store(sp, r3); sp++; }
+    if (n >= 3) { store(sp, r2); sp++; }
+    if (n >= 2) { store(sp, r1); sp++; }
+    return r0;
+  }
   // leaf step: pop if the leaf is exhausted
   __device__ __forceinline__ uint32_t pop_if(bool doit) {
     if (LDS_ONLY) {
@@ -286,10 +304,13 @@ __device__ __forceinline__ void wave_tick(unsigned lane, unsigned long long &c) 
 // ds_read with immediate offsets, and no "cached or not" test.  3 and 4: as 0 and 1 with
 // the packed 48-byte nodes (rtgpu_format.h): three loads per node step instead of four -
 // every node fetch of such a tree goes to memory, and the packed form is a quarter smaller.
+// 5 and 6: as 0 and 1 over the four-wide packed nodes (rtgpu_node4): a step tests up to four
+// children with six loads, and a ray takes about half as many dependent steps.
 template <int STATS, int REFILL, int MODE>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RTGPU_WAVES_PER_EU, RTGPU_WAVES_PER_EU)))
 void trace_kernel(const KParams P) {
-  constexpr bool LDS_ONLY = MODE == 1 || MODE == 2 || MODE == 4, SMALL = MODE == 2, PACKED = MODE >= 3;
+  constexpr bool LDS_ONLY = MODE == 1 || MODE == 2 || MODE == 4 || MODE == 6, SMALL = MODE == 2,
+                 PACKED = MODE == 3 || MODE == 4, WIDE = MODE >= 5;
   // LDS: [traversal stacks: stack_lds x kBlock u32][node cache: 4 planes x n_cached float4]
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   uint32_t *const lds_stack = smem;
@@ -360,7 +381,7 @@ void trace_kernel(const KParams P) {
   unsigned long long t_start = 0, t_dry = 0;
   if (STATS == 2) t_start = __builtin_amdgcn_s_memrealtime();
   // profile build: shader-clock cycles this wave spent per section of the outer loop
-  long long c_shade = 0, c_item = 0, c_gen = 0, c_setup = 0, c_trav = 0, c_mark = 0;
+  long long c_shade = 0, c_item = 0, c_gen = 0, c_setup = 0, c_trav = 0, c_mark = 0, c_nodes = 0, c_leaves = 0;
 #define SECTION_END(acc) do { if (STATS == 2) { long long t_ = (long long)clock64(); acc += t_ - c_mark; c_mark = t_; } } while (0)
   if (STATS == 2) c_mark = (long long)clock64();
 
@@ -653,9 +674,62 @@ void trace_kernel(const KParams P) {
       if (n_trav == 0 || (n_trav < REFILL && n_trav < n_entry)) break;  // wave-uniform
       int n_node = wave_count((int)cur >= 0);
       if (STATS == 2) { wave_tick(lane, w_trav); if ((int)cur != -1) l_trav++; }
+      long long c_phase = STATS == 2 ? (long long)clock64() : 0;
       if (2 * n_node >= n_trav) {
         do {
-          if ((int)cur >= 0) {
+          if (WIDE && (int)cur >= 0) {
+            if (STATS == 2) wave_tick(lane, w_node);
+            // 96-byte node at cur * 96 = (cur * 3) << 5: six loads, four children
+            uint32_t c3;
+            asm("v_lshl_add_u32 %0, %1, 1, %1" : "=v"(c3) : "v"(cur));
+            const float4 *n = (const float4 *)(nodes_base + (c3 << 5));
+            const float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3], q4 = n[4], q5 = n[5];
+            if (STATS) n_nodes++;
+            // children 0,1 sit in q0..q2 and children 2,3 in q3..q5 exactly as the two
+            // children of a BVH2 node sit in its first three quarters: the same six
+            // v_pk_fma_f32 per pair of children
+            float tn[4], tf[4];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+              const float4 a = h ? q3 : q0, b = h ? q4 : q1, c = h ? q5 : q2;
+              f2 p0 = __builtin_elementwise_fma(mk2(a.x, a.y), inv_xy, noi_xy);
+              f2 p1 = __builtin_elementwise_fma(mk2(a.z, a.w), inv_zx, noi_zx);
+              f2 p2 = __builtin_elementwise_fma(mk2(b.x, b.y), inv_yz, noi_yz);
+              f2 p3 = __builtin_elementwise_fma(mk2(b.z, b.w), inv_xy, noi_xy);
+              f2 p4 = __builtin_elementwise_fma(mk2(c.x, c.y), inv_zx, noi_zx);
+              f2 p5 = __builtin_elementwise_fma(mk2(c.z, c.w), inv_yz, noi_yz);
+              tn[2 * h] = fmax_(fmax_(fmin_(p0.x, p1.y), fmin_(p0.y, p2.x)), vmax_(fmin_(p1.x, p2.y), tmin));
+              tf[2 * h] = fmin_(fmin_(fmax_(p0.x, p1.y), fmax_(p0.y, p2.x)), vmin_(fmax_(p1.x, p2.y), tbest));
+              tn[2 * h + 1] = fmax_(fmax_(fmin_(p3.x, p4.y), fmin_(p3.y, p5.x)), vmax_(fmin_(p4.x, p5.y), tmin));
+              tf[2 * h + 1] = fmin_(fmin_(fmax_(p3.x, p4.y), fmax_(p3.y, p5.x)), vmin_(fmax_(p4.x, p5.y), tbest));
+            }
+            // references: byte j of child k = low byte of word 6k + j
+            auto lowbytes = [](float w0, float w1, float w2, float w3) {
+              const uint32_t lo = __builtin_amdgcn_perm(__float_as_uint(w1), __float_as_uint(w0), 0x0C0C0400u);
+              const uint32_t hi = __builtin_amdgcn_perm(__float_as_uint(w3), __float_as_uint(w2), 0x0C0C0400u);
+              return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+            };
+            uint32_t r0 = lowbytes(q0.x, q0.y, q0.z, q0.w), r1 = lowbytes(q1.z, q1.w, q2.x, q2.y),
+                     r2 = lowbytes(q3.x, q3.y, q3.z, q3.w), r3 = lowbytes(q4.z, q4.w, q5.x, q5.y);
+            // keys: ((bits of tnear) & ~3) | child for a hit, all ones for a miss; tnear >= tmin >= 0
+            const bool h0 = tn[0] <= tf[0], h1 = tn[1] <= tf[1], h2 = tn[2] <= tf[2], h3 = tn[3] <= tf[3];
+            uint32_t k0 = h0 ? ((__float_as_uint(tn[0]) & 0x7FFFFFFCu) | 0u) : 0xFFFFFFFFu;
+            uint32_t k1 = h1 ? ((__float_as_uint(tn[1]) & 0x7FFFFFFCu) | 1u) : 0xFFFFFFFFu;
+            uint32_t k2 = h2 ? ((__float_as_uint(tn[2]) & 0x7FFFFFFCu) | 2u) : 0xFFFFFFFFu;
+            uint32_t k3 = h3 ? ((__float_as_uint(tn[3]) & 0x7FFFFFFCu) | 3u) : 0xFFFFFFFFu;
+            const int n_hit = (int)h0 + (int)h1 + (int)h2 + (int)h3;
+            // five compare-exchanges on (key, reference) pairs: ascending keys
+#define RTGPU_CX(ka, ra, kb, rb) do { const bool sw_ = kb < ka; const uint32_t tk_ = sw_ ? kb : ka, tr_ = sw_ ? rb : ra; \
+                                       kb = sw_ ? ka : kb; rb = sw_ ? ra : rb; ka = tk_; ra = tr_; } while (0)
+            RTGPU_CX(k0, r0, k1, r1);
+            RTGPU_CX(k2, r2, k3, r3);
+            RTGPU_CX(k0, r0, k2, r2);
+            RTGPU_CX(k1, r1, k3, r3);
+            RTGPU_CX(k1, r1, k2, r2);
+#undef RTGPU_CX
+            cur = stk.step4(n_hit, r0, r1, r2, r3);
+          }
+          if (!WIDE && (int)cur >= 0) {
             if (STATS == 2) wave_tick(lane, w_node);
             float4 q0, q1, q2, q3;
             uint32_t c0, c1;
@@ -721,6 +795,7 @@ void trace_kernel(const KParams P) {
           }
           n_node = wave_count((int)cur >= 0);
         } while (n_node > 0 && 2 * n_node >= n_trav);
+        if (STATS == 2) c_nodes += (long long)clock64() - c_phase;
       } else {
         int n_leaf;
         do {
@@ -775,6 +850,7 @@ void trace_kernel(const KParams P) {
           }
           n_leaf = wave_count((int)cur < -1);
         } while (n_leaf > 0 && 2 * n_leaf > n_trav);
+        if (STATS == 2) c_leaves += (long long)clock64() - c_phase;
       }
     }
     SECTION_END(c_trav);
@@ -821,6 +897,8 @@ void trace_kernel(const KParams P) {
       atomicAdd(&P.counters[18], (unsigned long long)c_gen);
       atomicAdd(&P.counters[19], (unsigned long long)c_setup);
       atomicAdd(&P.counters[20], (unsigned long long)c_trav);
+      atomicAdd(&P.counters[21], (unsigned long long)c_nodes);   // of c_trav: node phases
+      atomicAdd(&P.counters[22], (unsigned long long)c_leaves);  // of c_trav: leaf phases
     }
   }
 }
@@ -919,6 +997,8 @@ struct rtgpu_ctx {
   void *d_nodes = nullptr, *d_tris = nullptr, *d_sphs = nullptr, *d_sph_meta = nullptr,
        *d_mats = nullptr;
   void *d_nodes48 = nullptr;    // packed nodes of a tree of >= RTGPU_NODE48_MIN_NODES nodes, else NULL
+  void *d_nodes4 = nullptr;     // four-wide packed nodes of such a tree (dropped by a refit), else NULL
+  bool no_wide = false;         // RTGPU_NO_WIDE=1: keep the BVH2 traversal on large trees (experiments)
   unsigned long long *d_counters = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
@@ -950,10 +1030,11 @@ namespace {
 // code path; the threshold only changes WHEN finished lanes are refilled, never
 // what a path computes.  RTGPU_REFILL (0/16/32) selects it for experiments.
 using KernelFn = void (*)(const KParams);
-constexpr int kModes = 5;
-struct Variant { int refill; KernelFn fn[3][kModes]; };  // [plain, stats, profile][MODE 0..4 of trace_kernel]
-#define RTGPU_VARIANT_ROW(S, R) \
-  {trace_kernel<S, R, 0>, trace_kernel<S, R, 1>, trace_kernel<S, R, 2>, trace_kernel<S, R, 3>, trace_kernel<S, R, 4>}
+constexpr int kModes = 7;
+struct Variant { int refill; KernelFn fn[3][kModes]; };  // [plain, stats, profile][MODE 0..6 of trace_kernel]
+#define RTGPU_VARIANT_ROW(S, R)                                                                         \
+  {trace_kernel<S, R, 0>, trace_kernel<S, R, 1>, trace_kernel<S, R, 2>, trace_kernel<S, R, 3>, trace_kernel<S, R, 4>, \
+   trace_kernel<S, R, 5>, trace_kernel<S, R, 6>}
 #define RTGPU_VARIANT(R) {R, {RTGPU_VARIANT_ROW(0, R), RTGPU_VARIANT_ROW(1, R), RTGPU_VARIANT_ROW(2, R)}}
 const Variant kVariants[] = {RTGPU_VARIANT(0), RTGPU_VARIANT(16), RTGPU_VARIANT(32)};
 // Default refill threshold, by what bounds the scene: 16 where the whole tree
@@ -975,7 +1056,8 @@ bool hip_fail(rtgpu_ctx *ctx, hipError_t e, const char *what) {
 void free_scene_device(rtgpu_ctx *ctx) {
   (void)hipFree(ctx->d_nodes);  (void)hipFree(ctx->d_tris);  (void)hipFree(ctx->d_sphs);
   (void)hipFree(ctx->d_sph_meta);  (void)hipFree(ctx->d_mats);  (void)hipFree(ctx->d_nodes48);
-  ctx->d_nodes = ctx->d_tris = ctx->d_sphs = ctx->d_sph_meta = ctx->d_mats = ctx->d_nodes48 = nullptr;
+  (void)hipFree(ctx->d_nodes4);
+  ctx->d_nodes = ctx->d_tris = ctx->d_sphs = ctx->d_sph_meta = ctx->d_mats = ctx->d_nodes48 = ctx->d_nodes4 = nullptr;
   rtgpu::free_flat_scene(&ctx->host);
   ctx->have_scene = false;
   ctx->host_stale = false;
@@ -1053,6 +1135,7 @@ extern "C" int rtgpu_create(rtgpu_ctx **out, int device_index) {
       if (kVariants[i].refill == want) ctx->variant = i;
   }
   if (const char *env = std::getenv("RTGPU_NO_NODE_CACHE")) ctx->no_node_cache = std::atoi(env) != 0;
+  if (const char *env = std::getenv("RTGPU_NO_WIDE")) ctx->no_wide = std::atoi(env) != 0;
   if (const char *env = std::getenv("RTGPU_STACK_LDS")) {
     int want = std::atoi(env);
     if (want >= 2 && want <= kStackLds) ctx->stack_lds = want;
@@ -1109,6 +1192,12 @@ extern "C" int rtgpu_upload_scene(rtgpu_ctx *ctx, const rtgpu_scene_desc *scene)
   HIP_TRY(ctx, hipDeviceSynchronize());
   free_scene_device(ctx);
   if (rtgpu::flatten_scene(scene, &ctx->host, ctx->err)) return 1;
+  if (ctx->no_wide && ctx->host.nodes4) {  // RTGPU_NO_WIDE: the oracle must see what the kernel traverses
+    std::free((void *)ctx->host.nodes4);
+    ctx->host.nodes4 = nullptr;
+    ctx->host.n_nodes4 = 0;
+    ctx->host.max_stack4 = 0;
+  }
   const rtgpu_flat_scene &h = ctx->host;
   // the +8 (+16 meta words) zeroed tail records of flatten_scene are uploaded too
   if (upload(ctx, &ctx->d_nodes, h.nodes, h.n_nodes * sizeof(rtgpu_node)) ||
@@ -1116,7 +1205,8 @@ extern "C" int rtgpu_upload_scene(rtgpu_ctx *ctx, const rtgpu_scene_desc *scene)
       upload(ctx, &ctx->d_sphs, h.spheres, (h.n_spheres + 8) * sizeof(rtgpu_sph)) ||
       upload(ctx, &ctx->d_sph_meta, h.sphere_meta, (h.n_spheres * 2 + 16) * sizeof(uint32_t)) ||
       upload(ctx, &ctx->d_mats, h.materials, h.n_materials * sizeof(rtgpu_material)) ||
-      (h.nodes48 && upload(ctx, &ctx->d_nodes48, h.nodes48, h.n_nodes * sizeof(rtgpu_node48)))) {
+      (h.nodes48 && upload(ctx, &ctx->d_nodes48, h.nodes48, h.n_nodes * sizeof(rtgpu_node48))) ||
+      (h.nodes4 && upload(ctx, &ctx->d_nodes4, h.nodes4, h.n_nodes4 * sizeof(rtgpu_node4)))) {
     std::string keep = ctx->err;
     free_scene_device(ctx);
     ctx->err = keep;
@@ -1184,6 +1274,16 @@ extern "C" int rtgpu_upload_scene_lbvh(rtgpu_ctx *ctx, const rtgpu_scene_desc *s
     ctx->err = keep;
     return 2;
   }
+  if (h.n_nodes >= RTGPU_NODE48_MIN_NODES && !ctx->no_wide) {  // four-wide nodes: collapsed on the host
+    std::string cerr;
+    h.nodes4 = rtgpu::collapse_nodes4((const rtgpu_node *)hn, h.n_nodes, &h.n_nodes4, &h.max_stack4, cerr);
+    if (!h.nodes4 || upload(ctx, &ctx->d_nodes4, h.nodes4, h.n_nodes4 * sizeof(rtgpu_node4))) {
+      std::string keep = h.nodes4 ? ctx->err : cerr;
+      free_scene_device(ctx);
+      ctx->err = keep;
+      return 2;
+    }
+  }
   ctx->have_scene = true;
   return 0;
 }
@@ -1210,6 +1310,13 @@ extern "C" int rtgpu_refit(rtgpu_ctx *ctx, const rtgpu_scene_desc *scene) {
   if (h.n_materials)
     HIP_TRY(ctx, hipMemcpy(ctx->d_mats, mats, h.n_materials * sizeof(rtgpu_material), hipMemcpyHostToDevice));
   ctx->host_stale = true;
+  // the four-wide nodes are not refitted: the loop falls back to the packed BVH2 until the next upload
+  (void)hipFree(ctx->d_nodes4);
+  ctx->d_nodes4 = nullptr;
+  std::free((void *)h.nodes4);
+  h.nodes4 = nullptr;
+  h.n_nodes4 = 0;
+  h.max_stack4 = 0;
   double ms = 0.0;
   int rc = rtgpu::refit_device(scene, ctx->d_nodes, h.n_nodes, ctx->d_tris, ctx->d_sphs, ctx->d_sph_meta, &ms, ctx->err);
   if (!rc && ctx->d_nodes48) rc = rtgpu::pack_nodes48_device(ctx->d_nodes, h.n_nodes, ctx->d_nodes48, ctx->err);
@@ -1273,7 +1380,12 @@ extern "C" int rtgpu_render_device(rtgpu_ctx *ctx, const rtgpu_camera *cam, cons
 
   KParams P;
   std::memset(&P, 0, sizeof(P));
-  P.nodes = (const float4 *)(ctx->d_nodes48 ? ctx->d_nodes48 : ctx->d_nodes);  // packed nodes when the tree has them
+  // four-wide nodes when the tree has them (and their stack fits), else packed BVH2 nodes, else the 64-byte ones
+  const uint32_t stack_fit_all = (uint32_t)(kLdsBytes / (kBlock * sizeof(uint32_t)));
+  const uint32_t need4 = ctx->host.max_stack4 + 4u;  // + sentinel + the three unconditional stores above the top
+  const uint32_t cap4 = ctx->stack_lds == kStackLds ? stack_fit_all : (uint32_t)ctx->stack_lds;
+  const bool wide = ctx->d_nodes4 != nullptr && need4 <= (cap4 < stack_fit_all ? cap4 : stack_fit_all) + (uint32_t)kStackOvf;
+  P.nodes = (const float4 *)(wide ? ctx->d_nodes4 : ctx->d_nodes48 ? ctx->d_nodes48 : ctx->d_nodes);
   P.tris = (const float4 *)ctx->d_tris;
   P.sphs = (const float4 *)ctx->d_sphs;
   P.sph_meta = (const uint2 *)ctx->d_sph_meta;
@@ -1306,9 +1418,10 @@ extern "C" int rtgpu_render_device(rtgpu_ctx *ctx, const rtgpu_camera *cam, cons
   // LDS budget of the one block per CU: the stack gets what the tree depth
   // needs (pushes never exceed the depth; +1 sentinel, +1 for the unconditional
   // store above the top).
-  uint32_t need = ctx->host.max_depth + 2u;
+  uint32_t need = wide ? need4 : ctx->host.max_depth + 2u;
   uint32_t stack_lds = need < 8u ? 8u : need;
-  if (stack_lds > (uint32_t)ctx->stack_lds) stack_lds = (uint32_t)ctx->stack_lds;  // kStackLds, or RTGPU_STACK_LDS
+  const uint32_t cap = wide ? cap4 : (uint32_t)ctx->stack_lds;  // kStackLds (the whole LDS for four-wide nodes), or RTGPU_STACK_LDS
+  if (stack_lds > cap) stack_lds = cap;
   const uint32_t stack_fit = (uint32_t)(kLdsBytes / (kBlock * sizeof(uint32_t)));      // entries the block's LDS share holds
   if (stack_lds > stack_fit) stack_lds = stack_fit;
   P.stack_lds = stack_lds;
@@ -1325,9 +1438,9 @@ extern "C" int rtgpu_render_device(rtgpu_ctx *ctx, const rtgpu_camera *cam, cons
     P.n_cached = (uint32_t)ctx->host.n_nodes;
     lds_bytes = stack_bytes + (size_t)kSmallNodes * sizeof(rtgpu_node);
   }
-  if (ctx->d_nodes48) {  // never a MODE 2 tree: RTGPU_NODE48_MIN_NODES > kSmallNodes
+  if (wide || ctx->d_nodes48) {  // never a MODE 2 tree: RTGPU_NODE48_MIN_NODES > kSmallNodes
     if (mode == 2) { ctx->err = "internal: packed nodes on a tree that fits the LDS cache"; return 2; }
-    mode += 3;
+    mode += wide ? 5 : 3;
   }
 
   bool want_stats = (s->flags & (RTGPU_FLAG_STATS | RTGPU_FLAG_PROFILE)) != 0;

@@ -116,3 +116,42 @@ def test_oracle_traverses_the_packed_nodes_and_sees_the_same_scene(ra, oracle):
     flat.c.nodes48 = keep
     assert np.array_equal(ia, ib) and np.array_equal(a.view(np.uint32), b.view(np.uint32))
     assert sa["rays"] == sb["rays"] and abs(sa["nodes"] - sb["nodes"]) < sb["nodes"] * 0.01
+
+
+def test_four_wide_nodes(ra, oracle):
+    """rtgpu_node4: present from the same threshold, structurally valid (every node and
+    primitive reached once, boxes nested, stack bound honoured), the oracle's four-wide
+    traversal finds the hits of the BVH2 in about half as many node steps, and a corrupted
+    node is caught."""
+    small = ra.FlatScene.build(ra.Scene.builtin(0)[0])
+    assert not small.c.nodes4 and small.c.n_nodes4 == 0
+    for kind, param in ((1, 5), (2, 3)):
+        scene, cam = ra.Scene.builtin(kind, param=param, aspect=1.5)
+        flat = ra.FlatScene.build(scene)
+        assert flat.c.nodes4 and flat.c.n_nodes // 3 <= flat.c.n_nodes4 <= flat.c.n_nodes
+        assert 3 <= flat.c.max_stack4 <= 3 * flat.c.max_depth
+        assert oracle.validate_bvh(flat.c)[0] == 0
+        st = ra.default_settings(96, 64, spp=2, max_depth=6)
+        oracle.lib.rto_debug_max_stack(1)
+        a, ia, sa = oracle.render(flat.c, cam, st, threads=4)
+        assert oracle.lib.rto_debug_max_stack(1) <= flat.c.max_stack4
+        keep = flat.c.nodes4
+        flat.c.nodes4 = None
+        b, ib, sb = oracle.render(flat.c, cam, st, threads=4)
+        flat.c.nodes4 = keep
+        assert np.array_equal(ia, ib) and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        assert sa["rays"] == sb["rays"] and 0.4 < sa["nodes"] / sb["nodes"] < 0.7
+        assert sa["tri_tests"] < sb["tri_tests"] * 1.05
+        # brute force over the same primitives agrees as well
+        c, ic, _ = oracle.render(flat.c, cam, st, brute_force=True, threads=4)
+        assert np.array_equal(ia, ic) and np.array_equal(a.view(np.uint32), c.view(np.uint32))
+    words = flat.nodes4_u32
+    bad = words.copy()
+    bad[3, 4] = np.float32(-1e30).view(np.uint32)     # child 0 of node 3: hi.y far below its lo
+    flat.c.nodes4 = bad.ctypes.data
+    assert oracle.validate_bvh(flat.c)[0] in (16, 17)
+    bad = words.copy()
+    bad[3, 0] ^= 0x01                                  # a reference byte: another node / primitive
+    flat.c.nodes4 = bad.ctypes.data
+    assert oracle.validate_bvh(flat.c)[0] != 0
+    flat.c.nodes4 = keep

@@ -21,5 +21,7 @@ for name in sys.argv[1:] or ["c2", "c3", "c5"]:
           f"   lane utilisation: shade={u(l_shade, w_shade):.3f} gen={u(paths, w_gen):.3f} node={u(nodes, w_node):.3f} "
           f"sph={u(sphs, w_sph):.3f} tri={u(tris, w_tri):.3f} trav_round={u(l_trav, w_trav):.3f}\n"
           f"   wave time share: " + " ".join(f"{n}={v / max(1, sum(cyc)):.3f}" for n, v in
-                                           zip(("shade", "item", "gen", "setup", "traversal"), cyc)), flush=True)
+                                           zip(("shade", "item", "gen", "setup", "traversal"), cyc))
+          + f"  (of traversal: node phases {c[21] / max(1, c[20]):.3f}, leaf phases {c[22] / max(1, c[20]):.3f};"
+          + f" cycles per node step {c[21] / max(1, w_node):.0f}, per leaf step {c[22] / max(1, w_sph + w_tri):.0f})", flush=True)
 ctx.close()

@@ -51,9 +51,10 @@ def main():
             ctx.render_device(cam, st, acc.data_ptr(), None, None)
             ms.append(ctx.kernel_ms())
         ms = np.array(ms)
-        node_bytes = 48 if fs.c.nodes48 else 64   # packed nodes from RTGPU_NODE48_MIN_NODES up
+        wide = f"/{fs.c.n_nodes4}x4" if fs.c.nodes4 else ""
+        node_bytes = 96 if fs.c.nodes4 else 48 if fs.c.nodes48 else 64   # four-wide / packed nodes from RTGPU_NODE48_MIN_NODES up
         abytes = node_bytes * s["nodes"] + 48 * s["tri_tests"] + 16 * s["sphere_tests"] + 32 * s["scatters"] + 16 * w * h
-        print(f"{name}: prims={scene.n_prims} nodes={fs.c.n_nodes} depth={fs.c.max_depth} gen={t1-t0:.1f}s "
+        print(f"{name}: prims={scene.n_prims} nodes={fs.c.n_nodes}{wide} depth={fs.c.max_depth} gen={t1-t0:.1f}s "
               f"build+upload={t2-t1:.1f}s (bvh {fs.c.build_ms:.1f} ms) | {w}x{h}x{spp} rays={s['rays']} "
               f"nodes/ray={s['nodes']/s['rays']:.1f} tris/ray={s['tri_tests']/s['rays']:.1f} "
               f"sph/ray={s['sphere_tests']/s['rays']:.1f} B/ray={abytes/s['rays']:.0f} | "
