@@ -7,11 +7,15 @@
 // it has fewer than four, the INNER child of largest surface area (ties: the
 // first), putting that child's two children in its place - so child order stays
 // the BVH2's left-to-right order and every box is one the BVH2 already stores.
-// Nodes are emitted parent first, children's subtrees in child order.
+// Nodes are emitted parent first, children's subtrees in child order, within the top
+// of the tree and within every subtree below it (built as parallel tasks).
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <system_error>
+#include <thread>
 #include <vector>
 
 #include "pack48.h"
@@ -31,16 +35,29 @@ inline float half_area(const Child &c) {
   return dx * dy + dy * dz + dz * dx;
 }
 
+// A node before packing: exact planes, references still to be finalised.  `ref` of an
+// inner child is an index LOCAL to the vector the node sits in (top part or one task).
+struct Tmp {
+  uint32_t w[24];
+  uint32_t ref[4];
+  uint8_t  n;         // children (2..4)
+  uint8_t  task[4];   // 1: ref[k] is a task id (top part only)
+};
+
 struct Collapser {
   const rtgpu_node *nodes;
   uint64_t n_nodes;
-  std::vector<rtgpu_node4> out;
+  std::vector<Tmp> out;
   uint32_t max_stack = 0;
   bool bad = false;
+  // top part only: subtrees below `task_level` node4 levels become tasks
+  int task_level = -1;
+  struct Task { uint32_t node2, above; };
+  std::vector<Task> *tasks = nullptr;
 
   // emits the node4 for the subtree under BVH2 node i; `above` = stack entries that can
   // lie below this node's own pushes (siblings of its ancestors)
-  uint32_t emit(uint32_t i, uint32_t above, uint32_t depth) {
+  uint32_t emit(uint32_t i, uint32_t above, uint32_t depth, int level) {
     if (i >= n_nodes || depth > RTGPU_MAX_TREE_DEPTH + 1) { bad = true; return 0; }
     Child ch[4];
     int n = 0;
@@ -52,6 +69,7 @@ struct Collapser {
     take(nodes[i], 0, ch[0]);
     take(nodes[i], 1, ch[1]);
     n = 2;
+    uint32_t d2 = depth + 1;  // BVH2 depth of the deepest absorbed child
     while (n < 4) {
       int best = -1;
       float best_area = -1.0f;
@@ -67,57 +85,126 @@ struct Collapser {
       take(nodes[r], 0, ch[best]);
       take(nodes[r], 1, ch[best + 1]);
       n++;
+      d2 = depth + 2;
     }
     const uint32_t me = (uint32_t)out.size();
     out.emplace_back();
     const uint32_t below = above + (uint32_t)(n - 1);
     if (below > max_stack) max_stack = below;
-    uint32_t refs[4];
-    for (int k = 0; k < n; k++)
-      refs[k] = (ch[k].ref & RTGPU_REF_LEAF) ? ch[k].ref : emit(ch[k].ref, below, depth + 1);
-    if (bad) return 0;
-    rtgpu_node4 nd;
+    Tmp t;
+    std::memset(&t, 0, sizeof(t));
+    t.n = (uint8_t)n;
     for (int k = 0; k < 4; k++) {
-      uint32_t w[6], ref = RTGPU_REF_EMPTY;
       if (k < n && ch[k].ref != RTGPU_REF_EMPTY) {
-        std::memcpy(w, ch[k].lo, 12);
-        std::memcpy(w + 3, ch[k].hi, 12);
-        ref = refs[k];
+        std::memcpy(&t.w[6 * k], ch[k].lo, 12);
+        std::memcpy(&t.w[6 * k + 3], ch[k].hi, 12);
+        if (ch[k].ref & RTGPU_REF_LEAF) {
+          t.ref[k] = ch[k].ref;
+        } else if (level == task_level) {
+          t.ref[k] = (uint32_t)tasks->size();
+          t.task[k] = 1;
+          tasks->push_back(Task{ch[k].ref, below});
+        } else {
+          t.ref[k] = emit(ch[k].ref, below, d2, level + 1);
+        }
       } else {
-        for (int j = 0; j < 6; j++) w[j] = RTGPU_NODE4_FAR;
+        for (int j = 0; j < 6; j++) t.w[6 * k + j] = RTGPU_NODE4_FAR;
+        t.ref[k] = RTGPU_REF_EMPTY;
       }
-      for (int j = 0; j < 4; j++)  // lo.x lo.y lo.z down, hi.x up
-        if (!embed_byte(w[j], (ref >> (8 * j)) & 0xFFu, j < 3, &w[j])) { bad = true; return 0; }
-      if ((w[4] & 0x7F800000u) == 0x7F800000u || (w[5] & 0x7F800000u) == 0x7F800000u) { bad = true; return 0; }
-      std::memcpy(&nd.w[6 * k], w, sizeof(w));
     }
-    out[me] = nd;
+    if (bad) return 0;
+    out[me] = t;
     return me;
   }
 };
+
+// planes + final references -> packed node; false if a plane has no packed form
+bool pack4(const Tmp &t, rtgpu_node4 *out) {
+  for (int k = 0; k < 4; k++) {
+    uint32_t w[6];
+    std::memcpy(w, &t.w[6 * k], sizeof(w));
+    for (int j = 0; j < 4; j++)  // lo.x lo.y lo.z down, hi.x up
+      if (!embed_byte(w[j], (t.ref[k] >> (8 * j)) & 0xFFu, j < 3, &w[j])) return false;
+    if ((w[4] & 0x7F800000u) == 0x7F800000u || (w[5] & 0x7F800000u) == 0x7F800000u) return false;
+    std::memcpy(&out->w[6 * k], w, sizeof(w));
+  }
+  return true;
+}
+
+// fn(t) for t in [0, n) on up to T threads (dynamic: one atomic counter)
+template <typename F>
+void parallel_for(size_t n, int T, F fn) {
+  std::atomic<size_t> next{0};
+  auto work = [&] { for (size_t t; (t = next.fetch_add(1)) < n;) fn(t); };
+  std::vector<std::thread> th;
+  for (int k = 1; k < T && (size_t)k < n; k++) {
+    try { th.emplace_back(work); } catch (const std::system_error &) { break; }
+  }
+  work();
+  for (auto &x : th) x.join();
+}
 
 }  // namespace
 
 // nodes (64-byte BVH2) -> four-wide packed nodes; malloc'ed, 64-byte aligned.  NULL with
 // err set if a plane has no packed form, the tree is malformed or memory runs out.
+// The top kTaskLevel + 1 node4 levels are collapsed on the calling thread; every subtree
+// below becomes a task (at most 4^(kTaskLevel+1) of them) built on its own into a private
+// vector, and the pieces are laid out [top][task 0][task 1]...: the bytes do not depend on
+// the number of threads.
 rtgpu_node4 *collapse_nodes4(const rtgpu_node *nodes, uint64_t n, uint64_t *n_out, uint32_t *max_stack,
                              std::string &err) {
-  Collapser C;
-  C.nodes = nodes;
-  C.n_nodes = n;
-  C.out.reserve((size_t)(n / 2 + 16));
-  uint32_t root = C.emit(0, 0, 0);
-  if (C.bad || root != 0) {
-    err = "four-wide nodes: malformed tree, or a box plane that is not finite / too close to FLT_MAX";
+  constexpr int kTaskLevel = 3;
+  constexpr int kThreads = 16;
+  const char *fail = "four-wide nodes: malformed tree, or a box plane that is not finite / too close to FLT_MAX";
+  Collapser top;
+  std::vector<Collapser::Task> tasks;
+  top.nodes = nodes;
+  top.n_nodes = n;
+  top.task_level = kTaskLevel;
+  top.tasks = &tasks;
+  uint32_t root = top.emit(0, 0, 0, 0);
+  if (top.bad || root != 0) { err = fail; return nullptr; }
+  std::vector<Collapser> sub(tasks.size());
+  parallel_for(tasks.size(), kThreads, [&](size_t t) {
+    sub[t].nodes = nodes;
+    sub[t].n_nodes = n;
+    sub[t].emit(tasks[t].node2, tasks[t].above, 0, 0);  // depth is re-counted from the task's root: the bound stays valid
+  });
+  std::vector<size_t> base(tasks.size() + 1);
+  base[0] = top.out.size();
+  uint32_t ms = top.max_stack;
+  for (size_t t = 0; t < tasks.size(); t++) {
+    if (sub[t].bad) { err = fail; return nullptr; }
+    base[t + 1] = base[t] + sub[t].out.size();
+    if (sub[t].max_stack > ms) ms = sub[t].max_stack;
+  }
+  const size_t total = base[tasks.size()];
+  if (total >= (1ull << 31) || total * sizeof(rtgpu_node4) >= (1ull << 32)) {
+    err = "four-wide nodes: buffer would reach 4 GiB";
     return nullptr;
   }
-  size_t bytes = (C.out.size() * sizeof(rtgpu_node4) + 63) / 64 * 64;
+  size_t bytes = (total * sizeof(rtgpu_node4) + 63) / 64 * 64;
   rtgpu_node4 *p = (rtgpu_node4 *)std::aligned_alloc(64, bytes);
   if (!p) { err = "out of host memory for the four-wide nodes"; return nullptr; }
-  std::memset(p, 0, bytes);
-  std::memcpy(p, C.out.data(), C.out.size() * sizeof(rtgpu_node4));
-  *n_out = C.out.size();
-  *max_stack = C.max_stack;
+  std::memset((char *)p + total * sizeof(rtgpu_node4), 0, bytes - total * sizeof(rtgpu_node4));
+  std::atomic<bool> bad{false};
+  // pieces: 0 = top part, 1 + t = task t
+  parallel_for(tasks.size() + 1, kThreads, [&](size_t piece) {
+    const std::vector<Tmp> &v = piece == 0 ? top.out : sub[piece - 1].out;
+    const size_t at = piece == 0 ? 0 : base[piece - 1];
+    for (size_t k = 0; k < v.size(); k++) {
+      Tmp t = v[k];
+      for (int c = 0; c < 4; c++) {
+        if (t.ref[c] & RTGPU_REF_LEAF) continue;  // leaves and EMPTY
+        t.ref[c] = t.task[c] ? (uint32_t)base[t.ref[c]] : (uint32_t)(at + t.ref[c]);
+      }
+      if (!pack4(t, &p[at + k])) bad = true;
+    }
+  });
+  if (bad) { std::free(p); err = fail; return nullptr; }
+  *n_out = total;
+  *max_stack = ms;
   return p;
 }
 
