@@ -158,6 +158,10 @@ typedef struct rtgpu_flat_scene {
   uint64_t       n_nodes4;
   uint32_t       max_stack4;   /* bound on the traversal stack over nodes4         */
   uint32_t       _pad2;
+  const uint32_t*nodes4_src;   /* 4 u32 per four-wide node: where child k's box lives
+                                  in `nodes` - (node index << 1) | child slot, or
+                                  0xFFFFFFFF for a missing child; a refit re-reads
+                                  the boxes through it                             */
 } rtgpu_flat_scene;
 
 typedef struct rtgpu_ctx rtgpu_ctx;

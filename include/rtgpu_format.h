@@ -57,8 +57,8 @@ typedef struct rtgpu_node48 {
  * down, hi.x up, < 256 floats); hi.y and hi.z are exact.  A missing child has the
  * reference RTGPU_REF_EMPTY and a box collapsed at RTGPU_NODE4_FAR on every axis,
  * which no ray reaches.  Present from RTGPU_NODE48_MIN_NODES BVH2 nodes up, and
- * then the array the trace loop and the oracle traverse (a refit drops it: the
- * loop falls back to the packed BVH2 until the next upload).
+ * then the array the trace loop and the oracle traverse (a refit keeps the
+ * collapse and re-reads every child box from the refitted BVH2).
  * Traversal order at a node: children whose slab test passes, by ascending key
  * ((bits of tnear) & 0x7FFFFFFC) | k - nearest first, the others pushed farthest
  * first. */

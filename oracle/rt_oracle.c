@@ -1026,7 +1026,7 @@ RTO_API void rto_flat_free(rtgpu_flat_scene *fs) {
   if (!fs) return;
   free((void *)fs->nodes); free((void *)fs->tris); free((void *)fs->spheres);
   free((void *)fs->sphere_meta); free((void *)fs->materials); free((void *)fs->nodes48);
-  free((void *)fs->nodes4);
+  free((void *)fs->nodes4); free((void *)fs->nodes4_src);
   memset(fs, 0, sizeof(*fs));
 }
 
@@ -1320,5 +1320,33 @@ RTO_API int rto_refit(const rtgpu_flat_scene *in, const rtgpu_scene_desc *sc, rt
   int pfail;
   out->nodes48 = pack_all(nodes, in->n_nodes, &pfail);
   if (pfail) return 4;
+  /* four-wide nodes: the collapse stays, every child box is re-read from the refitted
+   * BVH2 through the source map and packed again around the same reference */
+  if (in->nodes4 && in->nodes4_src) {
+    const size_t n4 = (size_t)in->n_nodes4;
+    rtgpu_node4 *w4 = malloc((n4 ? n4 : 1) * sizeof(rtgpu_node4));
+    uint32_t *src = malloc((n4 ? n4 : 1) * 16);
+    if (!w4 || !src) return 2;
+    memcpy(w4, in->nodes4, n4 * sizeof(rtgpu_node4));
+    memcpy(src, in->nodes4_src, n4 * 16);
+    for (size_t i = 0; i < n4; i++)
+      for (int k = 0; k < 4; k++) {
+        uint32_t sidx = src[4 * i + k];
+        if (sidx == 0xFFFFFFFFu) continue;
+        if ((sidx >> 1) >= nn) return 3;
+        uint32_t *w = &w4[i].w[6 * k];
+        uint32_t ref = (w[0] & 0xFFu) | ((w[1] & 0xFFu) << 8) | ((w[2] & 0xFFu) << 16) | ((w[3] & 0xFFu) << 24);
+        const rtgpu_node *b = &nodes[sidx >> 1];
+        memcpy(w, (sidx & 1u) ? b->lo1 : b->lo0, 12);
+        memcpy(w + 3, (sidx & 1u) ? b->hi1 : b->hi0, 12);
+        if ((w[4] & 0x7F800000u) == 0x7F800000u || (w[5] & 0x7F800000u) == 0x7F800000u) return 4;
+        for (int j = 0; j < 4; j++)
+          if (!pack_plane(w[j], (ref >> (8 * j)) & 0xFFu, j < 3, &w[j])) return 4;
+      }
+    out->nodes4 = w4;
+    out->nodes4_src = src;
+    out->n_nodes4 = in->n_nodes4;
+    out->max_stack4 = in->max_stack4;
+  }
   return 0;
 }

@@ -119,6 +119,7 @@ class FlatSceneC(C.Structure):
         ("nodes48", C.c_void_p),
         ("nodes4", C.c_void_p), ("n_nodes4", C.c_uint64),
         ("max_stack4", C.c_uint32), ("_pad2", C.c_uint32),
+        ("nodes4_src", C.c_void_p),
     ]
 
 
@@ -300,6 +301,12 @@ class FlatScene:
         if not self.c.nodes4:
             return np.zeros((0, 24), np.uint32)
         return self._view(self.c.nodes4, self.c.n_nodes4, np.uint32, 24)
+
+    @property
+    def nodes4_src(self):
+        if not self.c.nodes4_src:
+            return np.zeros((0, 4), np.uint32)
+        return self._view(self.c.nodes4_src, self.c.n_nodes4, np.uint32, 4)
 
     @property
     def tris_f32(self):

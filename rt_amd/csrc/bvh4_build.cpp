@@ -28,6 +28,7 @@ namespace {
 struct Child {
   float lo[3], hi[3];
   uint32_t ref;
+  uint32_t src;  // (BVH2 node << 1) | child slot: where this box is stored
 };
 
 inline float half_area(const Child &c) {
@@ -40,6 +41,7 @@ inline float half_area(const Child &c) {
 struct Tmp {
   uint32_t w[24];
   uint32_t ref[4];
+  uint32_t src[4];    // Child::src, 0xFFFFFFFF for a missing child
   uint8_t  n;         // children (2..4)
   uint8_t  task[4];   // 1: ref[k] is a task id (top part only)
 };
@@ -61,13 +63,15 @@ struct Collapser {
     if (i >= n_nodes || depth > RTGPU_MAX_TREE_DEPTH + 1) { bad = true; return 0; }
     Child ch[4];
     int n = 0;
-    auto take = [&](const rtgpu_node &nd, int which, Child &c) {
+    auto take = [&](uint32_t at, int which, Child &c) {
+      const rtgpu_node &nd = nodes[at];
       const float *lo = which ? nd.lo1 : nd.lo0, *hi = which ? nd.hi1 : nd.hi0;
       for (int k = 0; k < 3; k++) { c.lo[k] = lo[k]; c.hi[k] = hi[k]; }
       c.ref = which ? nd.child1 : nd.child0;
+      c.src = (at << 1) | (uint32_t)which;
     };
-    take(nodes[i], 0, ch[0]);
-    take(nodes[i], 1, ch[1]);
+    take(i, 0, ch[0]);
+    take(i, 1, ch[1]);
     n = 2;
     uint32_t d2 = depth + 1;  // BVH2 depth of the deepest absorbed child
     while (n < 4) {
@@ -82,8 +86,8 @@ struct Collapser {
       const uint32_t r = ch[best].ref;
       if (r >= n_nodes) { bad = true; return 0; }
       for (int k = n; k > best + 1; k--) ch[k] = ch[k - 1];  // open a slot after `best`
-      take(nodes[r], 0, ch[best]);
-      take(nodes[r], 1, ch[best + 1]);
+      take(r, 0, ch[best]);
+      take(r, 1, ch[best + 1]);
       n++;
       d2 = depth + 2;
     }
@@ -98,6 +102,7 @@ struct Collapser {
       if (k < n && ch[k].ref != RTGPU_REF_EMPTY) {
         std::memcpy(&t.w[6 * k], ch[k].lo, 12);
         std::memcpy(&t.w[6 * k + 3], ch[k].hi, 12);
+        t.src[k] = ch[k].src;
         if (ch[k].ref & RTGPU_REF_LEAF) {
           t.ref[k] = ch[k].ref;
         } else if (level == task_level) {
@@ -110,6 +115,7 @@ struct Collapser {
       } else {
         for (int j = 0; j < 6; j++) t.w[6 * k + j] = RTGPU_NODE4_FAR;
         t.ref[k] = RTGPU_REF_EMPTY;
+        t.src[k] = 0xFFFFFFFFu;
       }
     }
     if (bad) return 0;
@@ -153,7 +159,7 @@ void parallel_for(size_t n, int T, F fn) {
 // vector, and the pieces are laid out [top][task 0][task 1]...: the bytes do not depend on
 // the number of threads.
 rtgpu_node4 *collapse_nodes4(const rtgpu_node *nodes, uint64_t n, uint64_t *n_out, uint32_t *max_stack,
-                             std::string &err) {
+                             uint32_t **src_out, std::string &err) {
   constexpr int kTaskLevel = 3;
   constexpr int kThreads = 16;
   const char *fail = "four-wide nodes: malformed tree, or a box plane that is not finite / too close to FLT_MAX";
@@ -186,8 +192,11 @@ rtgpu_node4 *collapse_nodes4(const rtgpu_node *nodes, uint64_t n, uint64_t *n_ou
   }
   size_t bytes = (total * sizeof(rtgpu_node4) + 63) / 64 * 64;
   rtgpu_node4 *p = (rtgpu_node4 *)std::aligned_alloc(64, bytes);
-  if (!p) { err = "out of host memory for the four-wide nodes"; return nullptr; }
+  size_t src_bytes = (total * 16 + 63) / 64 * 64;
+  uint32_t *src = (uint32_t *)std::aligned_alloc(64, src_bytes);
+  if (!p || !src) { std::free(p); std::free(src); err = "out of host memory for the four-wide nodes"; return nullptr; }
   std::memset((char *)p + total * sizeof(rtgpu_node4), 0, bytes - total * sizeof(rtgpu_node4));
+  std::memset((char *)src + total * 16, 0, src_bytes - total * 16);
   std::atomic<bool> bad{false};
   // pieces: 0 = top part, 1 + t = task t
   parallel_for(tasks.size() + 1, kThreads, [&](size_t piece) {
@@ -200,9 +209,11 @@ rtgpu_node4 *collapse_nodes4(const rtgpu_node *nodes, uint64_t n, uint64_t *n_ou
         t.ref[c] = t.task[c] ? (uint32_t)base[t.ref[c]] : (uint32_t)(at + t.ref[c]);
       }
       if (!pack4(t, &p[at + k])) bad = true;
+      std::memcpy(&src[4 * (at + k)], t.src, 16);
     }
   });
-  if (bad) { std::free(p); err = fail; return nullptr; }
+  if (bad) { std::free(p); std::free(src); err = fail; return nullptr; }
+  *src_out = src;
   *n_out = total;
   *max_stack = ms;
   return p;

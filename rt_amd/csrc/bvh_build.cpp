@@ -631,7 +631,9 @@ int flatten_scene(const rtgpu_scene_desc *scene, rtgpu_flat_scene *out, std::str
   if (out->n_nodes >= RTGPU_NODE48_MIN_NODES) {
     out->nodes48 = pack_nodes48((const rtgpu_node *)out->nodes, out->n_nodes, err);
     if (!out->nodes48) { free_flat_scene(out); return 1; }
-    out->nodes4 = collapse_nodes4((const rtgpu_node *)out->nodes, out->n_nodes, &out->n_nodes4, &out->max_stack4, err);
+    uint32_t *src4 = nullptr;
+    out->nodes4 = collapse_nodes4((const rtgpu_node *)out->nodes, out->n_nodes, &out->n_nodes4, &out->max_stack4, &src4, err);
+    out->nodes4_src = src4;
     if (!out->nodes4) { free_flat_scene(out); return 1; }
   }
   out->build_ms =
@@ -648,6 +650,7 @@ void free_flat_scene(rtgpu_flat_scene *fs) {
   std::free((void *)fs->materials);
   std::free((void *)fs->nodes48);
   std::free((void *)fs->nodes4);
+  std::free((void *)fs->nodes4_src);
   std::memset(fs, 0, sizeof(*fs));
 }
 

@@ -20,7 +20,9 @@ rtgpu_material *flatten_materials(const rtgpu_scene_desc *scene);
 rtgpu_node48 *pack_nodes48(const rtgpu_node *nodes, uint64_t n, std::string &err);
 // bvh4_build.cpp: 64-byte BVH2 nodes -> four-wide packed nodes (malloc'ed; NULL + err on failure)
 rtgpu_node4 *collapse_nodes4(const rtgpu_node *nodes, uint64_t n, uint64_t *n_out, uint32_t *max_stack,
-                             std::string &err);
+                             uint32_t **src_out, std::string &err);
+// pack48.hip: four-wide nodes re-read from refitted 64-byte nodes through their source map, on the device
+int  refresh_nodes4_device(const void *d_nodes, void *d_nodes4, const void *d_src, uint64_t n4, std::string &err);
 // pack48.hip: the same on the device (d_bad: one u32, set non-zero if a node has no packed form)
 int  pack_nodes48_device(const void *d_nodes, uint64_t n, void *d_nodes48, std::string &err);
 

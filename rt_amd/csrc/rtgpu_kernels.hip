@@ -997,7 +997,8 @@ struct rtgpu_ctx {
   void *d_nodes = nullptr, *d_tris = nullptr, *d_sphs = nullptr, *d_sph_meta = nullptr,
        *d_mats = nullptr;
   void *d_nodes48 = nullptr;    // packed nodes of a tree of >= RTGPU_NODE48_MIN_NODES nodes, else NULL
-  void *d_nodes4 = nullptr;     // four-wide packed nodes of such a tree (dropped by a refit), else NULL
+  void *d_nodes4 = nullptr;     // four-wide packed nodes of such a tree, else NULL
+  void *d_nodes4_src = nullptr; // their source map (4 u32 per node), read by a refit
   bool no_wide = false;         // RTGPU_NO_WIDE=1: keep the BVH2 traversal on large trees (experiments)
   unsigned long long *d_counters = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -1056,8 +1057,9 @@ bool hip_fail(rtgpu_ctx *ctx, hipError_t e, const char *what) {
 void free_scene_device(rtgpu_ctx *ctx) {
   (void)hipFree(ctx->d_nodes);  (void)hipFree(ctx->d_tris);  (void)hipFree(ctx->d_sphs);
   (void)hipFree(ctx->d_sph_meta);  (void)hipFree(ctx->d_mats);  (void)hipFree(ctx->d_nodes48);
-  (void)hipFree(ctx->d_nodes4);
+  (void)hipFree(ctx->d_nodes4);  (void)hipFree(ctx->d_nodes4_src);
   ctx->d_nodes = ctx->d_tris = ctx->d_sphs = ctx->d_sph_meta = ctx->d_mats = ctx->d_nodes48 = ctx->d_nodes4 = nullptr;
+  ctx->d_nodes4_src = nullptr;
   rtgpu::free_flat_scene(&ctx->host);
   ctx->have_scene = false;
   ctx->host_stale = false;
@@ -1194,7 +1196,9 @@ extern "C" int rtgpu_upload_scene(rtgpu_ctx *ctx, const rtgpu_scene_desc *scene)
   if (rtgpu::flatten_scene(scene, &ctx->host, ctx->err)) return 1;
   if (ctx->no_wide && ctx->host.nodes4) {  // RTGPU_NO_WIDE: the oracle must see what the kernel traverses
     std::free((void *)ctx->host.nodes4);
+    std::free((void *)ctx->host.nodes4_src);
     ctx->host.nodes4 = nullptr;
+    ctx->host.nodes4_src = nullptr;
     ctx->host.n_nodes4 = 0;
     ctx->host.max_stack4 = 0;
   }
@@ -1206,7 +1210,8 @@ extern "C" int rtgpu_upload_scene(rtgpu_ctx *ctx, const rtgpu_scene_desc *scene)
       upload(ctx, &ctx->d_sph_meta, h.sphere_meta, (h.n_spheres * 2 + 16) * sizeof(uint32_t)) ||
       upload(ctx, &ctx->d_mats, h.materials, h.n_materials * sizeof(rtgpu_material)) ||
       (h.nodes48 && upload(ctx, &ctx->d_nodes48, h.nodes48, h.n_nodes * sizeof(rtgpu_node48))) ||
-      (h.nodes4 && upload(ctx, &ctx->d_nodes4, h.nodes4, h.n_nodes4 * sizeof(rtgpu_node4)))) {
+      (h.nodes4 && (upload(ctx, &ctx->d_nodes4, h.nodes4, h.n_nodes4 * sizeof(rtgpu_node4)) ||
+                    upload(ctx, &ctx->d_nodes4_src, h.nodes4_src, h.n_nodes4 * 16)))) {
     std::string keep = ctx->err;
     free_scene_device(ctx);
     ctx->err = keep;
@@ -1276,8 +1281,11 @@ extern "C" int rtgpu_upload_scene_lbvh(rtgpu_ctx *ctx, const rtgpu_scene_desc *s
   }
   if (h.n_nodes >= RTGPU_NODE48_MIN_NODES && !ctx->no_wide) {  // four-wide nodes: collapsed on the host
     std::string cerr;
-    h.nodes4 = rtgpu::collapse_nodes4((const rtgpu_node *)hn, h.n_nodes, &h.n_nodes4, &h.max_stack4, cerr);
-    if (!h.nodes4 || upload(ctx, &ctx->d_nodes4, h.nodes4, h.n_nodes4 * sizeof(rtgpu_node4))) {
+    uint32_t *src4 = nullptr;
+    h.nodes4 = rtgpu::collapse_nodes4((const rtgpu_node *)hn, h.n_nodes, &h.n_nodes4, &h.max_stack4, &src4, cerr);
+    h.nodes4_src = src4;
+    if (!h.nodes4 || upload(ctx, &ctx->d_nodes4, h.nodes4, h.n_nodes4 * sizeof(rtgpu_node4)) ||
+        upload(ctx, &ctx->d_nodes4_src, h.nodes4_src, h.n_nodes4 * 16)) {
       std::string keep = h.nodes4 ? ctx->err : cerr;
       free_scene_device(ctx);
       ctx->err = keep;
@@ -1310,16 +1318,11 @@ extern "C" int rtgpu_refit(rtgpu_ctx *ctx, const rtgpu_scene_desc *scene) {
   if (h.n_materials)
     HIP_TRY(ctx, hipMemcpy(ctx->d_mats, mats, h.n_materials * sizeof(rtgpu_material), hipMemcpyHostToDevice));
   ctx->host_stale = true;
-  // the four-wide nodes are not refitted: the loop falls back to the packed BVH2 until the next upload
-  (void)hipFree(ctx->d_nodes4);
-  ctx->d_nodes4 = nullptr;
-  std::free((void *)h.nodes4);
-  h.nodes4 = nullptr;
-  h.n_nodes4 = 0;
-  h.max_stack4 = 0;
   double ms = 0.0;
   int rc = rtgpu::refit_device(scene, ctx->d_nodes, h.n_nodes, ctx->d_tris, ctx->d_sphs, ctx->d_sph_meta, &ms, ctx->err);
   if (!rc && ctx->d_nodes48) rc = rtgpu::pack_nodes48_device(ctx->d_nodes, h.n_nodes, ctx->d_nodes48, ctx->err);
+  // the four-wide nodes keep their collapse: every child box is re-read from the refitted BVH2
+  if (!rc && ctx->d_nodes4) rc = rtgpu::refresh_nodes4_device(ctx->d_nodes, ctx->d_nodes4, ctx->d_nodes4_src, h.n_nodes4, ctx->err);
   if (rc) {  // the device arrays may be half rewritten: the scene is gone
     std::string keep = ctx->err;
     free_scene_device(ctx);
@@ -1339,7 +1342,8 @@ extern "C" int rtgpu_get_flat_scene(const rtgpu_ctx *ctx, rtgpu_flat_scene *out)
         hipMemcpy((void *)h.tris, ctx->d_tris, (size_t)h.n_tris * sizeof(rtgpu_tri), hipMemcpyDeviceToHost) != hipSuccess ||
         hipMemcpy((void *)h.spheres, ctx->d_sphs, (size_t)h.n_spheres * sizeof(rtgpu_sph), hipMemcpyDeviceToHost) != hipSuccess ||
         hipMemcpy((void *)h.sphere_meta, ctx->d_sph_meta, (size_t)h.n_spheres * 2 * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess ||
-        (h.nodes48 && hipMemcpy((void *)h.nodes48, ctx->d_nodes48, (size_t)h.n_nodes * sizeof(rtgpu_node48), hipMemcpyDeviceToHost) != hipSuccess))
+        (h.nodes48 && hipMemcpy((void *)h.nodes48, ctx->d_nodes48, (size_t)h.n_nodes * sizeof(rtgpu_node48), hipMemcpyDeviceToHost) != hipSuccess) ||
+        (h.nodes4 && hipMemcpy((void *)h.nodes4, ctx->d_nodes4, (size_t)h.n_nodes4 * sizeof(rtgpu_node4), hipMemcpyDeviceToHost) != hipSuccess))
       return 2;
     ctx->host_stale = false;
   }

@@ -29,7 +29,7 @@ def test_abi_version_and_struct_sizes(ra):
     assert C.sizeof(api.Settings) == 72
     assert C.sizeof(api.Stats) == 48
     assert C.sizeof(api.SceneDesc) == 48
-    assert C.sizeof(api.FlatSceneC) == 120
+    assert C.sizeof(api.FlatSceneC) == 128
     assert api.MATERIAL_DTYPE.itemsize == 32 and api.SPHERE_DTYPE.itemsize == 20
     assert api.TRIANGLE_DTYPE.itemsize == 40
 

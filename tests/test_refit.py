@@ -42,6 +42,12 @@ def _assert_same_bytes(a, b, what):
     fa, fb = _flat_bytes(a), _flat_bytes(b)
     for k in fa:
         assert fa[k] == fb[k], f"{what}: {k} differ"
+    # four-wide nodes and their source map, where both sides carry them
+    if a.nodes4 and b.nodes4:
+        assert (a.n_nodes4, a.max_stack4) == (b.n_nodes4, b.max_stack4), what
+        grab = lambda ptr, n: bytes((C.c_char * n).from_address(ptr))
+        assert grab(a.nodes4, a.n_nodes4 * 96) == grab(b.nodes4, b.n_nodes4 * 96), f"{what}: nodes4 differ"
+        assert grab(a.nodes4_src, a.n_nodes4 * 16) == grab(b.nodes4_src, b.n_nodes4 * 16), f"{what}: nodes4_src differ"
 
 
 def test_refit_with_unchanged_positions_reproduces_the_builders(ra, oracle):
@@ -66,6 +72,7 @@ def test_refit_keeps_the_topology_and_bounds_the_moved_geometry(ra, oracle):
         try:
             rc, depth = oracle.validate_bvh(there)
             assert rc == 0, f"{name}: validator code {rc}"
+            assert bool(there.nodes4) == bool(flat.c.nodes4) and there.n_nodes4 == flat.c.n_nodes4, name
             assert depth == flat.c.max_depth, name
             for a, b in zip(_topology(there), _topology(flat.c)):
                 assert np.array_equal(a, b), name
