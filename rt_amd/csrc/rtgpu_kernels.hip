@@ -232,10 +232,13 @@ struct Stack {
     if (LDS_ONLY || at < lds_entries) return lds[at * kBlock];
     return ovf[(size_t)(at - lds_entries) * ovf_stride];
   }
+  // the entry a pop would return (LDS form), read at the START of a node step so that the
+  // LDS round trip overlaps the node fetch instead of following the slab test
+  __device__ __forceinline__ uint32_t peek() const { return LDS_ONLY ? top_at[0] : 0u; }
   // node step: push `far_c` if both children were hit, pop if none was
-  __device__ __forceinline__ uint32_t step(bool both, bool none, uint32_t near_c, uint32_t far_c) {
+  __device__ __forceinline__ uint32_t step(bool both, bool none, uint32_t near_c, uint32_t far_c, uint32_t top) {
     if (LDS_ONLY) {
-      uint32_t top = top_at[0];   // one address: top at [0], free entry at [kBlock] (immediate offset)
+      // one address: top at [0] (read by peek()), free entry at [kBlock] (immediate offset)
       top_at[kBlock] = far_c;
       top_at += both ? kBlock : (none ? -kBlock : 0);
       return none ? top : near_c;
@@ -247,9 +250,8 @@ struct Stack {
   // four-wide node step: n children hit, r0 the nearest, r1..r3 the others by distance;
   // the others are pushed farthest first (the LDS form writes three entries whatever n is:
   // what lies above the new top is never read)
-  __device__ __forceinline__ uint32_t step4(int n, uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3) {
+  __device__ __forceinline__ uint32_t step4(int n, uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3, uint32_t top) {
     if (LDS_ONLY) {
-      uint32_t top = top_at[0];
       top_at[kBlock] = n == 4 ? r3 : (n == 3 ? r2 : r1);
       top_at[2 * kBlock] = n == 4 ? r2 : r1;
       top_at[3 * kBlock] = r1;
@@ -263,9 +265,8 @@ struct Stack {
     return r0;
   }
   // leaf step: pop if the leaf is exhausted
-  __device__ __forceinline__ uint32_t pop_if(bool doit) {
+  __device__ __forceinline__ uint32_t pop_if(bool doit, uint32_t top) {  // top = peek() at the start of the step
     if (LDS_ONLY) {
-      uint32_t top = top_at[0];
       top_at -= doit ? kBlock : 0;
       return top;
     }
@@ -683,6 +684,7 @@ void trace_kernel(const KParams P) {
             uint32_t c3;
             asm("v_lshl_add_u32 %0, %1, 1, %1" : "=v"(c3) : "v"(cur));
             const float4 *n = (const float4 *)(nodes_base + (c3 << 5));
+            const uint32_t top = stk.peek();
             const float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3], q4 = n[4], q5 = n[5];
             if (STATS) n_nodes++;
             // children 0,1 sit in q0..q2 and children 2,3 in q3..q5 exactly as the two
@@ -727,10 +729,11 @@ void trace_kernel(const KParams P) {
             RTGPU_CX(k1, r1, k3, r3);
             RTGPU_CX(k1, r1, k2, r2);
 #undef RTGPU_CX
-            cur = stk.step4(n_hit, r0, r1, r2, r3);
+            cur = stk.step4(n_hit, r0, r1, r2, r3, top);
           }
           if (!WIDE && (int)cur >= 0) {
             if (STATS == 2) wave_tick(lane, w_node);
+            const uint32_t top = stk.peek();
             float4 q0, q1, q2, q3;
             uint32_t c0, c1;
             // MODE 0/1 (tree larger than the LDS cache) fetch every node through L1: a
@@ -791,7 +794,7 @@ void trace_kernel(const KParams P) {
             bool swap = tn1 < tn0;
             uint32_t near_c = (h0 && !(h1 && swap)) ? c0 : c1;
             uint32_t far_c = swap ? c0 : c1;
-            cur = stk.step(h0 && h1, !(h0 || h1), near_c, far_c);
+            cur = stk.step(h0 && h1, !(h0 || h1), near_c, far_c, top);
           }
           n_node = wave_count((int)cur >= 0);
         } while (n_node > 0 && 2 * n_node >= n_trav);
@@ -804,6 +807,7 @@ void trace_kernel(const KParams P) {
           const bool at_tri = at_leaf && !(cur & RTGPU_REF_SPHERE);
           const uint32_t i = RTGPU_REF_FIRST(cur);
           const bool last = (cur & (7u << 27)) == 0u;  // count-1 == 0
+          const uint32_t top = stk.peek();
           if (at_sph) {
             float4 s = *(const float4 *)(sphs_base + (i << 4));
             if (STATS) n_sphs++;
@@ -845,7 +849,7 @@ void trace_kernel(const KParams P) {
           }
           if (at_leaf) {
             uint32_t next = cur + 1u - (1u << 27);  // first+1, count-1
-            uint32_t popped = stk.pop_if(last);
+            uint32_t popped = stk.pop_if(last, top);
             cur = last ? popped : next;
           }
           n_leaf = wave_count((int)cur < -1);
