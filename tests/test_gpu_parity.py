@@ -455,3 +455,35 @@ def test_emissive_materials(ra, oracle, gpu_ctx):
     for builder in ("sah", "lbvh"):
         with pytest.raises(ra.RtgpuError, match="material type"):
             gpu_ctx.upload(bad, builder=builder)
+
+
+def test_packed_bvh2_path_without_the_wide_nodes(ra, oracle, gpu_ctx):
+    """RTGPU_NO_WIDE=1 keeps large trees on the packed BVH2 nodes (kernel modes 3/4, the
+    path taken before the four-wide nodes existed): the flattened scene then carries no
+    four-wide nodes, the oracle follows, and the frame has the hits of the wide traversal."""
+    import os
+    scene, cam = ra.Scene.builtin(1, param=5, aspect=160 / 90)
+    st = ra.default_settings(160, 90, spp=2, max_depth=8)
+    (aw, iw, sw), (bw, ibw, sbw) = render_both(ra, oracle, gpu_ctx, scene, cam, st)
+    assert gpu_ctx.flat_scene().c.nodes4 and np.array_equal(iw, ibw) and sw == sbw
+    assert_bit_equal(aw, bw, "wide")
+    os.environ["RTGPU_NO_WIDE"] = "1"
+    try:
+        narrow = ra.Context(0)
+    finally:
+        del os.environ["RTGPU_NO_WIDE"]
+    try:
+        for builder in ("sah", "lbvh"):
+            narrow.upload(scene, builder=builder)
+            flat = narrow.flat_scene()
+            assert flat.c.nodes48 and not flat.c.nodes4
+            st_s = st.copy()
+            st_s.flags |= ra.FLAG_STATS
+            a, ia, sa = narrow.render(cam, st_s)
+            b, ib, sb = oracle.render(flat.c, cam, st, threads=16)
+            assert np.array_equal(ia, ib) and sa.as_dict() == sb
+            assert_bit_equal(a, b, f"packed BVH2 / {builder}")
+            if builder == "sah":
+                assert (ia == iw).mean() > 0.999 and sa.as_dict()["nodes"] > 1.5 * sw["nodes"]
+    finally:
+        narrow.close()
