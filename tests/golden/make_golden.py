@@ -12,7 +12,7 @@ Two kinds of fixture, kept apart on purpose:
                   rows a9/a10), so it is the only part that CAN be pinned by it.
 
   rng_kat.json, isect_kat.json, scatter_kat.json, s0_64x36.npz, checksums.json,
-  lit_box_48x48.npz
+  lit_box_48x48.npz, s1_level5_64x36.npz
                   outputs of THIS repo's CPU oracle (oracle/rt_oracle.c), for
                   which the reference has no counterpart ("parity unpinned",
                   SURVEY.md §8c).  They pin the oracle against regressions and
@@ -252,6 +252,23 @@ def make_lit_box(o):
     print("wrote lit_box_48x48.npz")
 
 
+def make_mesh(o):
+    # a tree large enough for the packed and four-wide nodes (S1 level 5: 20 k triangles,
+    # 11.9 k BVH2 nodes): what the trace loop traverses there is the four-wide array
+    scene, cam = ra.Scene.builtin(1, param=5, aspect=64 / 36)
+    fs = ra.FlatScene.build(scene)
+    assert fs.c.nodes4 and fs.c.nodes48
+    st = ra.default_settings(64, 36, spp=2, max_depth=8)
+    acc, ids, stats = o.render(fs.c, cam, st)
+    np.savez_compressed(os.path.join(HERE, "s1_level5_64x36.npz"), ids=ids, accum_2spp=acc.view(np.uint32),
+                        stats=np.array([stats[k] for k in sorted(stats)], np.uint64),
+                        stats_keys=np.array(sorted(stats)),
+                        n_nodes=np.array([fs.c.n_nodes, fs.c.n_nodes4, fs.c.max_stack4], np.uint64),
+                        nodes4_fnv=np.array([fnv1a_fast(fs.nodes4_u32)], np.uint64),
+                        nodes48_fnv=np.array([fnv1a_fast(fs.nodes48_u32)], np.uint64))
+    print("wrote s1_level5_64x36.npz")
+
+
 if __name__ == "__main__":
     o = Oracle()
     make_ref_math()
@@ -260,3 +277,4 @@ if __name__ == "__main__":
     make_scatter(o)
     make_images(o)
     make_lit_box(o)
+    make_mesh(o)

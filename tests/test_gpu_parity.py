@@ -72,6 +72,18 @@ def test_golden_fixture_without_oracle(ra, gpu_ctx):
     assert fs.c.n_nodes == chk["flat_s0"]["n_nodes"]
 
 
+def test_large_tree_fixture_without_oracle(ra, gpu_ctx):
+    """Committed vectors only: S1 level 5 through the four-wide nodes (kernel mode 6)."""
+    g = np.load(f"{GOLDEN}/s1_level5_64x36.npz")
+    scene, cam = ra.Scene.builtin(1, param=5, aspect=64 / 36)
+    gpu_ctx.upload(scene)
+    fs = gpu_ctx.flat_scene()
+    assert [fs.c.n_nodes, fs.c.n_nodes4, fs.c.max_stack4] == g["n_nodes"].tolist()
+    a, ids, st = gpu_ctx.render(cam, ra.default_settings(64, 36, spp=2, max_depth=8, flags=ra.FLAG_STATS))
+    assert np.array_equal(ids, g["ids"]) and np.array_equal(bits(a), g["accum_2spp"])
+    assert [st.as_dict()[k] for k in sorted(st.as_dict())] == g["stats"].tolist()
+
+
 @pytest.mark.parametrize("depth", [1, 8])
 def test_c1_frame(ra, oracle, gpu_ctx, depth):
     """BASELINE.json configs[0] frame (1280x720, 1 spp): checksums + oracle."""

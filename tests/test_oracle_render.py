@@ -211,3 +211,17 @@ def test_unknown_material_type_is_rejected(ra):
     bad = make_scene(ra, spheres=[(0, 0, 0, 1, 0)], materials=[(4, .5, .5, .5, 0)])
     with pytest.raises(ra.RtgpuError, match="material type"):
         ra.FlatScene.build(bad)
+
+
+def test_large_tree_fixture(ra, oracle):
+    """S1 level 5 (a tree with packed and four-wide nodes) against the committed frame:
+    pins the collapse, both packers and the four-wide traversal of the oracle."""
+    g = np.load(f"{GOLDEN}/s1_level5_64x36.npz")
+    scene, cam = ra.Scene.builtin(1, param=5, aspect=64 / 36)
+    fs = ra.FlatScene.build(scene)
+    assert [fs.c.n_nodes, fs.c.n_nodes4, fs.c.max_stack4] == g["n_nodes"].tolist()
+    assert fnv1a_words(fs.nodes4_u32) == int(g["nodes4_fnv"][0])
+    assert fnv1a_words(fs.nodes48_u32) == int(g["nodes48_fnv"][0])
+    acc, ids, stats = oracle.render(fs.c, cam, ra.default_settings(64, 36, spp=2, max_depth=8))
+    assert np.array_equal(ids, g["ids"]) and np.array_equal(bits(acc), g["accum_2spp"])
+    assert [stats[k] for k in sorted(stats)] == g["stats"].tolist()
