@@ -123,8 +123,8 @@ typedef struct rtgpu_settings {
                             * [k*chunk_samples, min((k+1)*chunk_samples, spp)) in
                             * order.  Finer chunks = shorter tail of the persistent
                             * kernel; the value is part of the arithmetic contract.
-                            * rtgpu_default_settings: 2 up to 128 spp, else
-                            * ceil(spp / 64); n chunks > 1 cost n x 16 B per pixel
+                            * rtgpu_default_settings: 2 below 16 spp, 4 up to 256
+                            * spp, else ceil(spp / 64); n chunks > 1 cost n x 16 B per pixel
                             * of context memory (the chunk planes) */
 } rtgpu_settings;
 

@@ -94,8 +94,10 @@ extern "C" void rtgpu_default_settings(rtgpu_settings *s, uint32_t width, uint32
   s->rank = 0;
   s->world_size = 1;
   s->flags = 0;
-  // 2 samples per work item measured best on C2/C3 (tools/gpu_perf.py, RT_CHUNK
-  // sweep); beyond 128 spp the chunks grow so that a frame never needs more than 64
-  // chunk planes (64 x 16 B per pixel of context memory)
-  s->chunk_samples = spp > 128u ? (spp + 63u) / 64u : 2u;
+  // Samples per work item (tools/gpu_chunk_sweep.py): 2 below 16 spp, where longer items
+  // would leave too few of them per lane and lengthen the tail of the launch; 4 from 16
+  // spp (half the queue traffic and chunk planes: C2 kernel 4.22 -> 4.17 ms, C3 at 64
+  // spp 24.2 -> 21.7 ms); beyond 256 spp the chunks grow so that a frame never needs
+  // more than 64 chunk planes (64 x 16 B per pixel of context memory)
+  s->chunk_samples = spp > 256u ? (spp + 63u) / 64u : (spp >= 16u ? 4u : 2u);
 }

@@ -65,10 +65,10 @@ def test_create_without_gpu_fails_cleanly(ra):
 
 def test_default_settings(ra):
     s = ra.default_settings(1920, 1080, spp=16, max_depth=8)
-    assert (s.width, s.height, s.spp, s.max_depth, s.seed, s.tile_size, s.world_size, s.chunk_samples) == (1920, 1080, 16, 8, 1, 64, 1, 2)
+    assert (s.width, s.height, s.spp, s.max_depth, s.seed, s.tile_size, s.world_size, s.chunk_samples) == (1920, 1080, 16, 8, 1, 64, 1, 4)
     assert np.float32(s.tmin) == np.float32(1e-3)
     assert list(s.sky_top) == [0.5, np.float32(0.7), 1.0] and list(s.sky_bottom) == [1.0, 1.0, 1.0]
-    # chunk rule: 2 samples per work item up to 128 spp, then at most 64 chunks per pixel
-    for spp, want in ((1, 2), (64, 2), (128, 2), (129, 3), (256, 4), (4096, 64)):
+    # chunk rule: 2 samples per work item below 16 spp, 4 up to 256 spp, then at most 64 chunks per pixel
+    for spp, want in ((1, 2), (15, 2), (16, 4), (64, 4), (128, 4), (256, 4), (257, 5), (4096, 64)):
         st = ra.default_settings(64, 64, spp=spp)
         assert st.chunk_samples == want and (spp + want - 1) // want <= 64
