@@ -197,6 +197,13 @@ int  rtgpu_upload_scene_lbvh(rtgpu_ctx *ctx, const rtgpu_scene_desc *scene);
  * has no BVH; §8f row 3 names builder + refit).  On a device error
  * the scene is dropped and must be uploaded again. */
 int  rtgpu_refit(rtgpu_ctx *ctx, const rtgpu_scene_desc *scene);
+/* The same for geometry that already lives in the memory of the context's GPU
+ * (arrays of rtgpu_sphere / rtgpu_triangle in the caller's order and with the
+ * uploaded counts; either may be NULL with a count of 0): nothing crosses PCIe.
+ * Materials stay as uploaded.  The input check of rtgpu_refit runs on the GPU
+ * before anything is rewritten; bad input leaves the scene intact. */
+int  rtgpu_refit_device(rtgpu_ctx *ctx, const void *d_spheres, uint64_t n_spheres,
+                        const void *d_triangles, uint64_t n_triangles);
 int  rtgpu_get_flat_scene(const rtgpu_ctx *ctx, rtgpu_flat_scene *out);
 
 /* Host-only variant of the two calls above: build + flatten without a GPU

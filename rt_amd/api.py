@@ -161,6 +161,7 @@ lib.rtgpu_default_settings.restype = None
 lib.rtgpu_scene_builtin.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, _P(SceneDesc), _P(Camera), C.c_float]
 lib.rtgpu_upload_scene_lbvh.argtypes = [C.c_void_p, _P(SceneDesc)]
 lib.rtgpu_refit.argtypes = [C.c_void_p, _P(SceneDesc)]
+lib.rtgpu_refit_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
 lib.rtgpu_scene_free.argtypes = [_P(SceneDesc)]
 lib.rtgpu_scene_free.restype = None
 lib.rtgpu_scene_parse_obj.argtypes = [C.c_char_p, C.c_uint64, _P(SceneDesc)]
@@ -366,6 +367,11 @@ class Context:
         """New positions / materials under the uploaded tree (rtgpu_refit): `scene` must
         hold the uploaded scene's counts, primitive i being the moved primitive i."""
         self._check(lib.rtgpu_refit(self._h, C.byref(scene.desc)))
+
+    def refit_device(self, spheres_ptr, n_spheres, triangles_ptr, n_triangles):
+        """rtgpu_refit_device: the moved primitives as device arrays (SPHERE_DTYPE /
+        TRIANGLE_DTYPE records, e.g. the data_ptr() of a torch uint8 tensor)."""
+        self._check(lib.rtgpu_refit_device(self._h, spheres_ptr, n_spheres, triangles_ptr, n_triangles))
 
     def flat_scene(self):
         fs = FlatSceneC()

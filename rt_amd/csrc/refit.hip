@@ -188,22 +188,71 @@ namespace rtgpu {
 // On an error return the device arrays may hold a mix of old and new records.
 int refit_device(const rtgpu_scene_desc *scene, void *d_nodes, uint64_t n_nodes, void *d_tris, void *d_sphs,
                  void *d_sph_meta, double *gpu_ms, std::string &err) {
-  const uint32_t ns = (uint32_t)scene->n_spheres, nt = (uint32_t)scene->n_triangles, P = ns + nt;
-  const uint32_t nn = (uint32_t)n_nodes;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  const uint32_t ns = (uint32_t)scene->n_spheres, nt = (uint32_t)scene->n_triangles;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;  // unused here: RF_TRY's clean-up names them
   DevBufs tmp;
   rtgpu_sphere *d_sph_in = nullptr;
   rtgpu_triangle *d_tri_in = nullptr;
-  uint32_t *d_done = nullptr, *d_count = nullptr, *d_list_a = nullptr, *d_list_b = nullptr, *d_bad = nullptr;
   RF_TRY(tmp.alloc(&d_sph_in, ns));
   RF_TRY(tmp.alloc(&d_tri_in, nt));
+  if (ns) RF_TRY(hipMemcpy(d_sph_in, scene->spheres, (size_t)ns * sizeof(rtgpu_sphere), hipMemcpyHostToDevice));
+  if (nt) RF_TRY(hipMemcpy(d_tri_in, scene->triangles, (size_t)nt * sizeof(rtgpu_triangle), hipMemcpyHostToDevice));
+  return refit_device_ptrs(d_sph_in, ns, d_tri_in, nt, d_nodes, n_nodes, d_tris, d_sphs, d_sph_meta, gpu_ms, err);
+}
+
+// Input check for primitives that only exist on the device (rtgpu_refit_device): what
+// validate_scene checks on the host.  Runs BEFORE anything is rewritten.
+__global__ __launch_bounds__(kThreads) void check_prims(const rtgpu_sphere *sph, uint32_t ns, const rtgpu_triangle *tri,
+                                                         uint32_t nt, uint32_t n_materials, uint32_t *bad) {
+  for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < ns + nt; i += gridDim.x * kThreads) {
+    bool ok;
+    if (i < ns) {
+      const rtgpu_sphere s = sph[i];
+      ok = s.material < n_materials && s.radius > 0.f && isfinite(s.radius) && isfinite(s.center[0]) &&
+           isfinite(s.center[1]) && isfinite(s.center[2]);
+    } else {
+      const rtgpu_triangle t = tri[i - ns];
+      ok = t.material < n_materials;
+      for (int k = 0; k < 3; k++) ok = ok && isfinite(t.v0[k]) && isfinite(t.v1[k]) && isfinite(t.v2[k]);
+    }
+    if (!ok) atomicOr(bad, 1u);
+  }
+}
+
+int check_prims_device(const void *d_sph_in, uint32_t ns, const void *d_tri_in, uint32_t nt, uint32_t n_materials,
+                       std::string &err) {
+  if (ns + nt == 0) return 0;
+  uint32_t *d_bad = nullptr, bad = 0;
+  hipError_t e = hipMalloc((void **)&d_bad, sizeof(uint32_t));
+  if (e == hipSuccess) e = hipMemset(d_bad, 0, sizeof(uint32_t));
+  if (e == hipSuccess) {
+    unsigned blocks = std::min<unsigned>((unsigned)(((size_t)ns + nt + kThreads - 1) / kThreads), 4096u);
+    hipLaunchKernelGGL(check_prims, dim3(blocks), dim3(kThreads), 0, 0, (const rtgpu_sphere *)d_sph_in, ns,
+                       (const rtgpu_triangle *)d_tri_in, nt, n_materials, d_bad);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpy(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost);
+  (void)hipFree(d_bad);
+  if (e != hipSuccess) { err = std::string("refit: input check: ") + hipGetErrorString(e); return 2; }
+  if (bad) { err = "refit: a primitive has a non-finite coordinate, a non-positive radius or a material index out of range"; return 1; }
+  return 0;
+}
+
+// The same with the caller's primitive arrays already on the device.
+int refit_device_ptrs(const void *d_sph_in_, uint32_t ns, const void *d_tri_in_, uint32_t nt, void *d_nodes,
+                      uint64_t n_nodes, void *d_tris, void *d_sphs, void *d_sph_meta, double *gpu_ms, std::string &err) {
+  const rtgpu_sphere *d_sph_in = (const rtgpu_sphere *)d_sph_in_;
+  const rtgpu_triangle *d_tri_in = (const rtgpu_triangle *)d_tri_in_;
+  const uint32_t P = ns + nt;
+  const uint32_t nn = (uint32_t)n_nodes;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  DevBufs tmp;
+  uint32_t *d_done = nullptr, *d_count = nullptr, *d_list_a = nullptr, *d_list_b = nullptr, *d_bad = nullptr;
   RF_TRY(tmp.alloc(&d_done, nn));
   RF_TRY(tmp.alloc(&d_count, kCounts));
   RF_TRY(tmp.alloc(&d_list_a, nn));
   RF_TRY(tmp.alloc(&d_list_b, nn));
   RF_TRY(tmp.alloc(&d_bad, 1));
-  if (ns) RF_TRY(hipMemcpy(d_sph_in, scene->spheres, (size_t)ns * sizeof(rtgpu_sphere), hipMemcpyHostToDevice));
-  if (nt) RF_TRY(hipMemcpy(d_tri_in, scene->triangles, (size_t)nt * sizeof(rtgpu_triangle), hipMemcpyHostToDevice));
   RF_TRY(hipMemset(d_done, 0, (size_t)(nn ? nn : 1) * sizeof(uint32_t)));
   RF_TRY(hipMemset(d_count, 0, kCounts * sizeof(uint32_t)));
   RF_TRY(hipMemset(d_bad, 0, sizeof(uint32_t)));

@@ -39,6 +39,12 @@ void free_lbvh(LbvhDevice *out);
 // refit.hip: new geometry under the uploaded tree's topology, in place on the device arrays
 int  refit_device(const rtgpu_scene_desc *scene, void *d_nodes, uint64_t n_nodes, void *d_tris, void *d_sphs,
                   void *d_sph_meta, double *gpu_ms, std::string &err);
+// the same with the caller's rtgpu_sphere / rtgpu_triangle arrays already in device memory, and the
+// input check that validate_scene does on the host (0 = fine, 1 = bad primitive, 2 = device error)
+int  refit_device_ptrs(const void *d_spheres, uint32_t ns, const void *d_triangles, uint32_t nt, void *d_nodes,
+                       uint64_t n_nodes, void *d_tris, void *d_sphs, void *d_sph_meta, double *gpu_ms, std::string &err);
+int  check_prims_device(const void *d_spheres, uint32_t ns, const void *d_triangles, uint32_t nt, uint32_t n_materials,
+                        std::string &err);
 
 // host_util.cpp
 void set_global_error(const std::string &msg);

@@ -1337,6 +1337,41 @@ extern "C" int rtgpu_refit(rtgpu_ctx *ctx, const rtgpu_scene_desc *scene) {
   return 0;
 }
 
+// rtgpu_refit for geometry that already lives on the GPU (an animation or simulation
+// step wrote it there): nothing crosses PCIe.  Materials stay as uploaded.
+extern "C" int rtgpu_refit_device(rtgpu_ctx *ctx, const void *d_spheres, uint64_t n_spheres,
+                                  const void *d_triangles, uint64_t n_triangles) {
+  if (!ctx) return 1;
+  if (ctx->pending) { ctx->err = "a frame begun with rtgpu_render_begin is pending (call rtgpu_render_end)"; return 1; }
+  if (!ctx->have_scene) { ctx->err = "no scene uploaded (call rtgpu_upload_scene first)"; return 1; }
+  rtgpu_flat_scene &h = ctx->host;
+  if (n_spheres != h.n_spheres || n_triangles != h.n_tris) {
+    ctx->err = "refit: the scene must hold the sphere and triangle counts of the uploaded one";
+    return 1;
+  }
+  if ((n_spheres && !d_spheres) || (n_triangles && !d_triangles)) { ctx->err = "refit: NULL device array with a non-zero count"; return 1; }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  // what validate_scene checks on the host, before anything is rewritten
+  if (int rc = rtgpu::check_prims_device(d_spheres, (uint32_t)n_spheres, d_triangles, (uint32_t)n_triangles,
+                                         (uint32_t)h.n_materials, ctx->err))
+    return rc;
+  ctx->host_stale = true;
+  double ms = 0.0;
+  int rc = rtgpu::refit_device_ptrs(d_spheres, (uint32_t)n_spheres, d_triangles, (uint32_t)n_triangles, ctx->d_nodes,
+                                    h.n_nodes, ctx->d_tris, ctx->d_sphs, ctx->d_sph_meta, &ms, ctx->err);
+  if (!rc && ctx->d_nodes48) rc = rtgpu::pack_nodes48_device(ctx->d_nodes, h.n_nodes, ctx->d_nodes48, ctx->err);
+  if (!rc && ctx->d_nodes4) rc = rtgpu::refresh_nodes4_device(ctx->d_nodes, ctx->d_nodes4, ctx->d_nodes4_src, h.n_nodes4, ctx->err);
+  if (rc) {  // the device arrays may be half rewritten: the scene is gone
+    std::string keep = ctx->err;
+    free_scene_device(ctx);
+    ctx->err = keep + " (scene dropped, upload again)";
+    return rc;
+  }
+  h.build_ms = ms;
+  return 0;
+}
+
 extern "C" int rtgpu_get_flat_scene(const rtgpu_ctx *ctx, rtgpu_flat_scene *out) {
   if (!ctx || !out || !ctx->have_scene) return 1;
   if (ctx->host_stale) {

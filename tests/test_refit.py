@@ -165,3 +165,36 @@ def test_refit_rejects_bad_input_and_keeps_the_scene(ra, gpu_ctx):
             fresh.refit(scene)
     finally:
         fresh.close()
+
+
+@pytest.mark.gpu
+def test_refit_from_device_arrays(ra, oracle, gpu_ctx):
+    """rtgpu_refit_device: the moved primitives handed over as GPU arrays give the bytes of
+    the host-pointer refit (and of the restatement); bad input found by the on-device
+    check leaves the scene intact."""
+    import torch
+    for name in ("random mixed", "S1 level 5 (20k tris)"):
+        scene = _scenes(ra)[name]
+        moved = _moved(ra, scene, seed=5)
+        moved = ra.Scene(moved.spheres, moved.triangles, scene.materials)   # materials stay as uploaded
+        for builder in ("sah", "lbvh"):
+            gpu_ctx.upload(scene, builder=builder)
+            want = oracle.refit(gpu_ctx.flat_scene().c, moved.desc)
+            try:
+                d_sph = torch.from_numpy(moved.spheres.view(np.uint8).copy()).cuda()
+                d_tri = torch.from_numpy(moved.triangles.view(np.uint8).copy()).cuda()
+                gpu_ctx.refit_device(d_sph.data_ptr() if len(moved.spheres) else None, len(moved.spheres),
+                                     d_tri.data_ptr() if len(moved.triangles) else None, len(moved.triangles))
+                _assert_same_bytes(gpu_ctx.flat_scene().c, want, f"{name} / {builder} / device arrays")
+                # bad input: caught on the GPU before anything is rewritten
+                bad = moved.triangles.copy()
+                bad["v1"][7, 1] = np.inf
+                d_bad = torch.from_numpy(bad.view(np.uint8).copy()).cuda()
+                with pytest.raises(ra.RtgpuError, match="non-finite"):
+                    gpu_ctx.refit_device(d_sph.data_ptr() if len(moved.spheres) else None, len(moved.spheres),
+                                         d_bad.data_ptr(), len(bad))
+                with pytest.raises(ra.RtgpuError, match="counts"):
+                    gpu_ctx.refit_device(None, 0, d_tri.data_ptr(), len(moved.triangles) - 1)
+                _assert_same_bytes(gpu_ctx.flat_scene().c, want, f"{name} / {builder} / after rejected input")
+            finally:
+                oracle.free_flat(want)
