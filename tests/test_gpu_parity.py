@@ -499,3 +499,41 @@ def test_packed_bvh2_path_without_the_wide_nodes(ra, oracle, gpu_ctx):
                 assert (ia == iw).mean() > 0.999 and sa.as_dict()["nodes"] > 1.5 * sw["nodes"]
     finally:
         narrow.close()
+
+
+def test_settings_fuzz(ra, oracle, gpu_ctx):
+    """Seeded random settings on three scenes (small tree in LDS, mixed soup, a tree with
+    four-wide nodes): frame sizes that are no multiple of anything, tile sizes, ranks,
+    sample offsets, chunk sizes, depth, seed, tmin, lens, sky, accumulation onto a
+    non-zero frame - GPU against oracle, bit for bit, counters included."""
+    rng = np.random.default_rng(2024)
+    soup = _random_scene(ra, np.random.default_rng(9), 60, 80)
+    scenes = [ra.Scene.builtin(0)[0], soup, ra.Scene.builtin(1, param=5)[0]]
+    for trial in range(48):
+        scene = scenes[trial % 3]
+        w, h = int(rng.integers(9, 140)), int(rng.integers(9, 90))
+        world = int(rng.choice([1, 1, 2, 3, 5]))
+        spp = int(rng.integers(1, 12))
+        kw = dict(spp=spp, max_depth=int(rng.integers(1, 10)), tile_size=int(rng.choice([8, 16, 32, 64])),
+                  rank=int(rng.integers(0, world)), world_size=world, seed=int(rng.integers(0, 2**31)),
+                  sample_offset=int(rng.integers(0, 1000)), chunk_samples=int(rng.integers(1, 7)),
+                  tmin=float(rng.choice([0.0, 1e-4, 1e-3, 5e-2])),
+                  sky_bottom=tuple(rng.uniform(0, 1, 3)), sky_top=tuple(rng.uniform(0, 1, 3)))
+        accumulate = bool(rng.integers(0, 2))
+        flags = (ra.FLAG_ACCUMULATE if accumulate else 0)
+        cam = ra.look_at(tuple(rng.uniform(-6, 6, 3) + np.array([0, 3, 0])), tuple(rng.uniform(-1, 1, 3)),
+                         vfov=float(rng.uniform(15, 80)), aspect=w / h,
+                         aperture=float(rng.choice([0.0, 0.0, 0.2])), focus_dist=float(rng.uniform(2, 12)))
+        st = ra.default_settings(w, h, flags=flags, **kw)
+        start = rng.uniform(0, 3, (h, w, 4)).astype(np.float32) if accumulate else np.zeros((h, w, 4), np.float32)
+        gpu_ctx.upload(scene, builder="lbvh" if trial % 4 == 3 else "sah")
+        st_s = st.copy()
+        st_s.flags |= ra.FLAG_STATS
+        a, ia, sa = gpu_ctx.render(cam, st_s, accum=start.copy())
+        b, ib, sb = oracle.render(gpu_ctx.flat_scene().c, cam, st, accum=start.copy(), threads=8)
+        what = f"trial {trial}: {w}x{h} {kw} accumulate={accumulate}"
+        owned = ia != ra.NO_HIT  # ids of pixels this rank does not own stay NO_HIT on both sides
+        assert np.array_equal(ia, ib), what
+        assert_bit_equal(a, b, what)
+        assert sa.as_dict() == sb, what
+        assert world == 1 or not owned.all()
