@@ -46,11 +46,13 @@ __global__ __launch_bounds__(256) void refresh4_kernel(const rtgpu_node *nodes, 
 
 namespace rtgpu {
 
-// The current device must be the context's.  Synchronous.
-int refresh_nodes4_device(const void *d_nodes, void *d_nodes4, const void *d_src, uint64_t n4, std::string &err) {
+// The current device must be the context's.  Synchronous.  d_flag: one u32 of device
+// scratch the caller keeps, or NULL to allocate it here.
+int refresh_nodes4_device(const void *d_nodes, void *d_nodes4, const void *d_src, uint64_t n4, uint32_t *d_flag,
+                          std::string &err) {
   if (n4 == 0) return 0;
-  uint32_t *d_bad = nullptr, bad = 0;
-  hipError_t e = hipMalloc((void **)&d_bad, sizeof(uint32_t));
+  uint32_t *d_bad = d_flag, bad = 0;
+  hipError_t e = d_flag ? hipSuccess : hipMalloc((void **)&d_bad, sizeof(uint32_t));
   if (e == hipSuccess) e = hipMemset(d_bad, 0, sizeof(uint32_t));
   if (e == hipSuccess) {
     unsigned blocks = (unsigned)((n4 + 255) / 256);
@@ -60,17 +62,17 @@ int refresh_nodes4_device(const void *d_nodes, void *d_nodes4, const void *d_src
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipMemcpy(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost);
-  (void)hipFree(d_bad);
+  if (!d_flag) (void)hipFree(d_bad);
   if (e != hipSuccess) { err = std::string("refresh4: ") + hipGetErrorString(e); return 2; }
   if (bad) { err = "a box plane is not finite or too close to FLT_MAX for the four-wide node format"; return 1; }
   return 0;
 }
 
 // The current device must be the context's.  Synchronous.
-int pack_nodes48_device(const void *d_nodes, uint64_t n, void *d_nodes48, std::string &err) {
+int pack_nodes48_device(const void *d_nodes, uint64_t n, void *d_nodes48, uint32_t *d_flag, std::string &err) {
   if (n == 0) return 0;
-  uint32_t *d_bad = nullptr, bad = 0;
-  hipError_t e = hipMalloc((void **)&d_bad, sizeof(uint32_t));
+  uint32_t *d_bad = d_flag, bad = 0;
+  hipError_t e = d_flag ? hipSuccess : hipMalloc((void **)&d_bad, sizeof(uint32_t));
   if (e == hipSuccess) e = hipMemset(d_bad, 0, sizeof(uint32_t));
   if (e == hipSuccess) {
     unsigned blocks = (unsigned)((n + 255) / 256);
@@ -80,7 +82,7 @@ int pack_nodes48_device(const void *d_nodes, uint64_t n, void *d_nodes48, std::s
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipMemcpy(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost);
-  (void)hipFree(d_bad);
+  if (!d_flag) (void)hipFree(d_bad);
   if (e != hipSuccess) { err = std::string("pack48: ") + hipGetErrorString(e); return 2; }
   if (bad) { err = "a box plane is not finite or too close to FLT_MAX for the packed node format"; return 1; }
   return 0;

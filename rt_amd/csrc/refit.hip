@@ -186,8 +186,10 @@ namespace rtgpu {
 // The current device must be the context's; `scene` must have passed validate_scene
 // and hold the counts the device arrays were built from (the caller checks both).
 // On an error return the device arrays may hold a mix of old and new records.
+size_t refit_workspace_words(uint64_t n_nodes) { return 3 * (size_t)(n_nodes ? n_nodes : 1) + kCounts + 4; }
+
 int refit_device(const rtgpu_scene_desc *scene, void *d_nodes, uint64_t n_nodes, void *d_tris, void *d_sphs,
-                 void *d_sph_meta, double *gpu_ms, std::string &err) {
+                 void *d_sph_meta, uint32_t *ws, double *gpu_ms, std::string &err) {
   const uint32_t ns = (uint32_t)scene->n_spheres, nt = (uint32_t)scene->n_triangles;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;  // unused here: RF_TRY's clean-up names them
   DevBufs tmp;
@@ -197,7 +199,7 @@ int refit_device(const rtgpu_scene_desc *scene, void *d_nodes, uint64_t n_nodes,
   RF_TRY(tmp.alloc(&d_tri_in, nt));
   if (ns) RF_TRY(hipMemcpy(d_sph_in, scene->spheres, (size_t)ns * sizeof(rtgpu_sphere), hipMemcpyHostToDevice));
   if (nt) RF_TRY(hipMemcpy(d_tri_in, scene->triangles, (size_t)nt * sizeof(rtgpu_triangle), hipMemcpyHostToDevice));
-  return refit_device_ptrs(d_sph_in, ns, d_tri_in, nt, d_nodes, n_nodes, d_tris, d_sphs, d_sph_meta, gpu_ms, err);
+  return refit_device_ptrs(d_sph_in, ns, d_tri_in, nt, d_nodes, n_nodes, d_tris, d_sphs, d_sph_meta, ws, gpu_ms, err);
 }
 
 // Input check for primitives that only exist on the device (rtgpu_refit_device): what
@@ -220,10 +222,10 @@ __global__ __launch_bounds__(kThreads) void check_prims(const rtgpu_sphere *sph,
 }
 
 int check_prims_device(const void *d_sph_in, uint32_t ns, const void *d_tri_in, uint32_t nt, uint32_t n_materials,
-                       std::string &err) {
+                       uint32_t *d_flag, std::string &err) {
   if (ns + nt == 0) return 0;
-  uint32_t *d_bad = nullptr, bad = 0;
-  hipError_t e = hipMalloc((void **)&d_bad, sizeof(uint32_t));
+  uint32_t *d_bad = d_flag, bad = 0;
+  hipError_t e = d_flag ? hipSuccess : hipMalloc((void **)&d_bad, sizeof(uint32_t));
   if (e == hipSuccess) e = hipMemset(d_bad, 0, sizeof(uint32_t));
   if (e == hipSuccess) {
     unsigned blocks = std::min<unsigned>((unsigned)(((size_t)ns + nt + kThreads - 1) / kThreads), 4096u);
@@ -232,15 +234,18 @@ int check_prims_device(const void *d_sph_in, uint32_t ns, const void *d_tri_in, 
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipMemcpy(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost);
-  (void)hipFree(d_bad);
+  if (!d_flag) (void)hipFree(d_bad);
   if (e != hipSuccess) { err = std::string("refit: input check: ") + hipGetErrorString(e); return 2; }
   if (bad) { err = "refit: a primitive has a non-finite coordinate, a non-positive radius or a material index out of range"; return 1; }
   return 0;
 }
 
-// The same with the caller's primitive arrays already on the device.
+// The same with the caller's primitive arrays already on the device.  `ws`: scratch of
+// refit_workspace_words(n_nodes) words that a caller keeps between refits (the context
+// does, so a frame loop pays no hipMalloc / hipFree), or NULL to allocate it here.
 int refit_device_ptrs(const void *d_sph_in_, uint32_t ns, const void *d_tri_in_, uint32_t nt, void *d_nodes,
-                      uint64_t n_nodes, void *d_tris, void *d_sphs, void *d_sph_meta, double *gpu_ms, std::string &err) {
+                      uint64_t n_nodes, void *d_tris, void *d_sphs, void *d_sph_meta, uint32_t *ws, double *gpu_ms,
+                      std::string &err) {
   const rtgpu_sphere *d_sph_in = (const rtgpu_sphere *)d_sph_in_;
   const rtgpu_triangle *d_tri_in = (const rtgpu_triangle *)d_tri_in_;
   const uint32_t P = ns + nt;
@@ -248,11 +253,13 @@ int refit_device_ptrs(const void *d_sph_in_, uint32_t ns, const void *d_tri_in_,
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   DevBufs tmp;
   uint32_t *d_done = nullptr, *d_count = nullptr, *d_list_a = nullptr, *d_list_b = nullptr, *d_bad = nullptr;
-  RF_TRY(tmp.alloc(&d_done, nn));
-  RF_TRY(tmp.alloc(&d_count, kCounts));
-  RF_TRY(tmp.alloc(&d_list_a, nn));
-  RF_TRY(tmp.alloc(&d_list_b, nn));
-  RF_TRY(tmp.alloc(&d_bad, 1));
+  if (!ws) RF_TRY(tmp.alloc(&ws, refit_workspace_words(n_nodes)));
+  const size_t stride = nn ? nn : 1;
+  d_done = ws;
+  d_list_a = ws + stride;
+  d_list_b = ws + 2 * stride;
+  d_count = ws + 3 * stride;
+  d_bad = d_count + kCounts;
   RF_TRY(hipMemset(d_done, 0, (size_t)(nn ? nn : 1) * sizeof(uint32_t)));
   RF_TRY(hipMemset(d_count, 0, kCounts * sizeof(uint32_t)));
   RF_TRY(hipMemset(d_bad, 0, sizeof(uint32_t)));

@@ -22,9 +22,10 @@ rtgpu_node48 *pack_nodes48(const rtgpu_node *nodes, uint64_t n, std::string &err
 rtgpu_node4 *collapse_nodes4(const rtgpu_node *nodes, uint64_t n, uint64_t *n_out, uint32_t *max_stack,
                              uint32_t **src_out, std::string &err);
 // pack48.hip: four-wide nodes re-read from refitted 64-byte nodes through their source map, on the device
-int  refresh_nodes4_device(const void *d_nodes, void *d_nodes4, const void *d_src, uint64_t n4, std::string &err);
-// pack48.hip: the same on the device (d_bad: one u32, set non-zero if a node has no packed form)
-int  pack_nodes48_device(const void *d_nodes, uint64_t n, void *d_nodes48, std::string &err);
+int  refresh_nodes4_device(const void *d_nodes, void *d_nodes4, const void *d_src, uint64_t n4, uint32_t *d_flag,
+                           std::string &err);
+// pack48.hip: pack_nodes48 on the device (d_flag: one u32 of device scratch, or NULL to allocate it there)
+int  pack_nodes48_device(const void *d_nodes, uint64_t n, void *d_nodes48, uint32_t *d_flag, std::string &err);
 
 // lbvh_build.hip: the same flattened scene built on the GPU (device arrays, caller frees with free_lbvh)
 struct LbvhDevice {
@@ -37,14 +38,17 @@ int  lbvh_build_device(const rtgpu_scene_desc *scene, LbvhDevice *out, std::stri
 void free_lbvh(LbvhDevice *out);
 
 // refit.hip: new geometry under the uploaded tree's topology, in place on the device arrays
+// (ws: device scratch of refit_workspace_words(n_nodes) u32 kept between refits, or NULL)
+size_t refit_workspace_words(uint64_t n_nodes);
 int  refit_device(const rtgpu_scene_desc *scene, void *d_nodes, uint64_t n_nodes, void *d_tris, void *d_sphs,
-                  void *d_sph_meta, double *gpu_ms, std::string &err);
+                  void *d_sph_meta, uint32_t *ws, double *gpu_ms, std::string &err);
 // the same with the caller's rtgpu_sphere / rtgpu_triangle arrays already in device memory, and the
 // input check that validate_scene does on the host (0 = fine, 1 = bad primitive, 2 = device error)
 int  refit_device_ptrs(const void *d_spheres, uint32_t ns, const void *d_triangles, uint32_t nt, void *d_nodes,
-                       uint64_t n_nodes, void *d_tris, void *d_sphs, void *d_sph_meta, double *gpu_ms, std::string &err);
+                       uint64_t n_nodes, void *d_tris, void *d_sphs, void *d_sph_meta, uint32_t *ws, double *gpu_ms,
+                       std::string &err);
 int  check_prims_device(const void *d_spheres, uint32_t ns, const void *d_triangles, uint32_t nt, uint32_t n_materials,
-                        std::string &err);
+                        uint32_t *d_flag, std::string &err);
 
 // host_util.cpp
 void set_global_error(const std::string &msg);

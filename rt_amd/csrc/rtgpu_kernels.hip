@@ -1003,6 +1003,7 @@ struct rtgpu_ctx {
   void *d_nodes48 = nullptr;    // packed nodes of a tree of >= RTGPU_NODE48_MIN_NODES nodes, else NULL
   void *d_nodes4 = nullptr;     // four-wide packed nodes of such a tree, else NULL
   void *d_nodes4_src = nullptr; // their source map (4 u32 per node), read by a refit
+  uint32_t *d_refit_ws = nullptr; // refit scratch (3 u32 per node), allocated by the first refit of a scene
   bool no_wide = false;         // RTGPU_NO_WIDE=1: keep the BVH2 traversal on large trees (experiments)
   unsigned long long *d_counters = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -1061,12 +1062,20 @@ bool hip_fail(rtgpu_ctx *ctx, hipError_t e, const char *what) {
 void free_scene_device(rtgpu_ctx *ctx) {
   (void)hipFree(ctx->d_nodes);  (void)hipFree(ctx->d_tris);  (void)hipFree(ctx->d_sphs);
   (void)hipFree(ctx->d_sph_meta);  (void)hipFree(ctx->d_mats);  (void)hipFree(ctx->d_nodes48);
-  (void)hipFree(ctx->d_nodes4);  (void)hipFree(ctx->d_nodes4_src);
+  (void)hipFree(ctx->d_nodes4);  (void)hipFree(ctx->d_nodes4_src);  (void)hipFree(ctx->d_refit_ws);
+  ctx->d_refit_ws = nullptr;
   ctx->d_nodes = ctx->d_tris = ctx->d_sphs = ctx->d_sph_meta = ctx->d_mats = ctx->d_nodes48 = ctx->d_nodes4 = nullptr;
   ctx->d_nodes4_src = nullptr;
   rtgpu::free_flat_scene(&ctx->host);
   ctx->have_scene = false;
   ctx->host_stale = false;
+}
+
+// scratch the refits of this scene share: allocated once, freed with the scene
+int refit_workspace(rtgpu_ctx *ctx) {
+  if (ctx->d_refit_ws) return 0;
+  HIP_TRY(ctx, hipMalloc((void **)&ctx->d_refit_ws, rtgpu::refit_workspace_words(ctx->host.n_nodes) * sizeof(uint32_t)));
+  return 0;
 }
 
 int upload(rtgpu_ctx *ctx, void **dst, const void *src, size_t bytes) {
@@ -1261,7 +1270,7 @@ extern "C" int rtgpu_upload_scene_lbvh(rtgpu_ctx *ctx, const rtgpu_scene_desc *s
       return 2;
     }
     std::string perr;
-    if (int prc = rtgpu::pack_nodes48_device(ctx->d_nodes, h.n_nodes, ctx->d_nodes48, perr)) {
+    if (int prc = rtgpu::pack_nodes48_device(ctx->d_nodes, h.n_nodes, ctx->d_nodes48, nullptr, perr)) {
       free_scene_device(ctx);
       ctx->err = perr;
       return prc;
@@ -1321,12 +1330,14 @@ extern "C" int rtgpu_refit(rtgpu_ctx *ctx, const rtgpu_scene_desc *scene) {
   h.materials = mats;
   if (h.n_materials)
     HIP_TRY(ctx, hipMemcpy(ctx->d_mats, mats, h.n_materials * sizeof(rtgpu_material), hipMemcpyHostToDevice));
+  if (refit_workspace(ctx)) return 2;
+  uint32_t *flag = ctx->d_refit_ws + rtgpu::refit_workspace_words(h.n_nodes) - 1;  // last word: the packers' flag
   ctx->host_stale = true;
   double ms = 0.0;
-  int rc = rtgpu::refit_device(scene, ctx->d_nodes, h.n_nodes, ctx->d_tris, ctx->d_sphs, ctx->d_sph_meta, &ms, ctx->err);
-  if (!rc && ctx->d_nodes48) rc = rtgpu::pack_nodes48_device(ctx->d_nodes, h.n_nodes, ctx->d_nodes48, ctx->err);
+  int rc = rtgpu::refit_device(scene, ctx->d_nodes, h.n_nodes, ctx->d_tris, ctx->d_sphs, ctx->d_sph_meta, ctx->d_refit_ws, &ms, ctx->err);
+  if (!rc && ctx->d_nodes48) rc = rtgpu::pack_nodes48_device(ctx->d_nodes, h.n_nodes, ctx->d_nodes48, flag, ctx->err);
   // the four-wide nodes keep their collapse: every child box is re-read from the refitted BVH2
-  if (!rc && ctx->d_nodes4) rc = rtgpu::refresh_nodes4_device(ctx->d_nodes, ctx->d_nodes4, ctx->d_nodes4_src, h.n_nodes4, ctx->err);
+  if (!rc && ctx->d_nodes4) rc = rtgpu::refresh_nodes4_device(ctx->d_nodes, ctx->d_nodes4, ctx->d_nodes4_src, h.n_nodes4, flag, ctx->err);
   if (rc) {  // the device arrays may be half rewritten: the scene is gone
     std::string keep = ctx->err;
     free_scene_device(ctx);
@@ -1352,16 +1363,18 @@ extern "C" int rtgpu_refit_device(rtgpu_ctx *ctx, const void *d_spheres, uint64_
   if ((n_spheres && !d_spheres) || (n_triangles && !d_triangles)) { ctx->err = "refit: NULL device array with a non-zero count"; return 1; }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipDeviceSynchronize());
+  if (refit_workspace(ctx)) return 2;
+  uint32_t *flag = ctx->d_refit_ws + rtgpu::refit_workspace_words(h.n_nodes) - 1;  // last word: the checks' and packers' flag
   // what validate_scene checks on the host, before anything is rewritten
   if (int rc = rtgpu::check_prims_device(d_spheres, (uint32_t)n_spheres, d_triangles, (uint32_t)n_triangles,
-                                         (uint32_t)h.n_materials, ctx->err))
+                                         (uint32_t)h.n_materials, flag, ctx->err))
     return rc;
   ctx->host_stale = true;
   double ms = 0.0;
   int rc = rtgpu::refit_device_ptrs(d_spheres, (uint32_t)n_spheres, d_triangles, (uint32_t)n_triangles, ctx->d_nodes,
-                                    h.n_nodes, ctx->d_tris, ctx->d_sphs, ctx->d_sph_meta, &ms, ctx->err);
-  if (!rc && ctx->d_nodes48) rc = rtgpu::pack_nodes48_device(ctx->d_nodes, h.n_nodes, ctx->d_nodes48, ctx->err);
-  if (!rc && ctx->d_nodes4) rc = rtgpu::refresh_nodes4_device(ctx->d_nodes, ctx->d_nodes4, ctx->d_nodes4_src, h.n_nodes4, ctx->err);
+                                    h.n_nodes, ctx->d_tris, ctx->d_sphs, ctx->d_sph_meta, ctx->d_refit_ws, &ms, ctx->err);
+  if (!rc && ctx->d_nodes48) rc = rtgpu::pack_nodes48_device(ctx->d_nodes, h.n_nodes, ctx->d_nodes48, flag, ctx->err);
+  if (!rc && ctx->d_nodes4) rc = rtgpu::refresh_nodes4_device(ctx->d_nodes, ctx->d_nodes4, ctx->d_nodes4_src, h.n_nodes4, flag, ctx->err);
   if (rc) {  // the device arrays may be half rewritten: the scene is gone
     std::string keep = ctx->err;
     free_scene_device(ctx);
