@@ -15,8 +15,8 @@ if [ "$1" = build ]; then
     set -- $cfg
     ( cd rt_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -std=c++17 -O3 -fPIC -ffp-contract=off -fno-fast-math \
         -fno-slp-vectorize -I../../include -I. -DRTGPU_KBLOCK=$1 -DRTGPU_BLOCKS_PER_CU=$2 -DRTGPU_WAVES_PER_EU=$3 -c -o build/k_exp.o rtgpu_kernels.hip &&
-      /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../librtgpu_x$1x$2w$3.so build/k_exp.o build/lbvh_build.o \
-        build/bvh_build.o build/host_util.o build/scenes.o build/scene_io.o -lpthread )
+      /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../librtgpu_x$1x$2w$3.so build/k_exp.o \
+        $(ls build/*.o | grep -v -e k_exp.o -e rtgpu_kernels.o) -lpthread )
     echo "built rt_amd/librtgpu_x$1x$2w$3.so"
   done
 else
