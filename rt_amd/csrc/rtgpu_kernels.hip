@@ -40,9 +40,13 @@ namespace {
 #ifndef RTGPU_BLOCKS_PER_CU
 #define RTGPU_BLOCKS_PER_CU 1
 #endif
+#ifndef RTGPU_TRI_STEP
+#define RTGPU_TRI_STEP 2
+#endif
 #ifndef RTGPU_WAVES_PER_EU
 #define RTGPU_WAVES_PER_EU (RTGPU_KBLOCK * RTGPU_BLOCKS_PER_CU / 256)
 #endif
+constexpr int      kTriStep    = RTGPU_TRI_STEP;   // triangles a lane tests per leaf step (trees outside LDS)
 constexpr int      kBlock      = RTGPU_KBLOCK;
 constexpr int      kBlocksPerCU = RTGPU_BLOCKS_PER_CU; // one block per CU: 16 waves share one LDS copy of the top of the BVH
 constexpr int      kStackLds   = 32;   // most entries per lane the LDS stack may get (4 KiB per entry per block)
@@ -310,8 +314,9 @@ __device__ __forceinline__ void wave_tick(unsigned lane, unsigned long long &c) 
 template <int STATS, int REFILL, int MODE>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RTGPU_WAVES_PER_EU, RTGPU_WAVES_PER_EU)))
 void trace_kernel(const KParams P) {
-  constexpr bool LDS_ONLY = MODE == 1 || MODE == 2 || MODE == 4 || MODE == 6, SMALL = MODE == 2,
+  constexpr bool LDS_ONLY = MODE == 1 || MODE == 2 || MODE == 4 || MODE == 6, SMALL = MODE == 2, 
                  PACKED = MODE == 3 || MODE == 4, WIDE = MODE >= 5;
+  constexpr int TRIS = MODE == 2 ? 1 : kTriStep;  // triangles per leaf step (two in the LDS mode measured C2 1.4 % slower)
   // LDS: [traversal stacks: stack_lds x kBlock u32][node cache: 4 planes x n_cached float4]
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   uint32_t *const lds_stack = smem;
@@ -806,7 +811,6 @@ void trace_kernel(const KParams P) {
           const bool at_sph = at_leaf && (cur & RTGPU_REF_SPHERE);
           const bool at_tri = at_leaf && !(cur & RTGPU_REF_SPHERE);
           const uint32_t i = RTGPU_REF_FIRST(cur);
-          const bool last = (cur & (7u << 27)) == 0u;  // count-1 == 0
           const uint32_t top = stk.peek();
           if (at_sph) {
             float4 s = *(const float4 *)(sphs_base + (i << 4));
@@ -824,33 +828,52 @@ void trace_kernel(const KParams P) {
             t = ok ? t : t2;
             if (ok || ok2) { tbest = t; hit_ref = cur; }
           }
+          // a lane tests up to kTriStep of the triangles left in its leaf per step (all
+          // records requested before the first test): same tests in the same order, fewer
+          // dependent round trips
+          const uint32_t left = (cur >> 27) & 7u;                                    // triangles after this one
+          const uint32_t more = TRIS > 1 && at_tri ? (left < (uint32_t)(TRIS - 1) ? left : (uint32_t)(TRIS - 1)) : 0u;
           if (at_tri) {
             // i * 48 as (i * 3) << 4 with the * 3 spelled as one v_lshl_add_u32: hipcc turns any
             // C spelling back into v_mul_lo_u32, which is quarter rate.  32-bit offset: < 4 GiB of triangles
             uint32_t i3;
             asm("v_lshl_add_u32 %0, %1, 1, %1" : "=v"(i3) : "v"(i));
             const float4 *tp = (const float4 *)(tris_base + (i3 << 4));
-            float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
-            if (STATS) n_tris++;
+            float4 rec[TRIS][3];
+#pragma unroll
+            for (int k = 0; k < TRIS; k++) {
+              // a lane with fewer triangles left re-reads its last one (never past the array)
+              const float4 *tq = tp + 3u * ((uint32_t)k < more ? (uint32_t)k : more);
+              rec[k][0] = tq[0]; rec[k][1] = tq[1]; rec[k][2] = tq[2];
+            }
+            if (STATS) n_tris += 1u + more;
             if (STATS == 2) wave_tick(lane, w_tri);
-            V3 v0 = mk(t0.x, t0.y, t0.z), e1 = mk(t1.x, t1.y, t1.z), e2 = mk(t2.x, t2.y, t2.z);
-            V3 pvec = cross(rd, e2);
-            float det = dot(e1, pvec);
-            bool valid = !(__builtin_fabsf(det) < 1e-30f);
-            float inv_det = rcp_exact(det);
-            V3 tvec = ro - v0;
-            float u = dot(tvec, pvec) * inv_det;
-            valid = valid && !(u < 0.0f || u > 1.0f);
-            V3 qvec = cross(tvec, e1);
-            float v = dot(rd, qvec) * inv_det;
-            valid = valid && !(v < 0.0f || u + v > 1.0f);
-            float t = dot(e2, qvec) * inv_det;
-            if (valid && t > tmin && t < tbest) { tbest = t; hit_ref = cur; }
+#pragma unroll
+            for (int k = 0; k < TRIS; k++) {
+              if (k == 0 || (uint32_t)k <= more) {
+                const float4 a = rec[k][0], b = rec[k][1], c = rec[k][2];
+                V3 v0 = mk(a.x, a.y, a.z), e1 = mk(b.x, b.y, b.z), e2 = mk(c.x, c.y, c.z);
+                V3 pvec = cross(rd, e2);
+                float det = dot(e1, pvec);
+                bool valid = !(__builtin_fabsf(det) < 1e-30f);
+                float inv_det = rcp_exact(det);
+                V3 tvec = ro - v0;
+                float u = dot(tvec, pvec) * inv_det;
+                valid = valid && !(u < 0.0f || u > 1.0f);
+                V3 qvec = cross(tvec, e1);
+                float v = dot(rd, qvec) * inv_det;
+                valid = valid && !(v < 0.0f || u + v > 1.0f);
+                float t = dot(e2, qvec) * inv_det;
+                // the leaf cursor as it stands at this test: first + k, count - k
+                if (valid && t > tmin && t < tbest) { tbest = t; hit_ref = cur + (uint32_t)k - ((uint32_t)k << 27); }
+              }
+            }
           }
           if (at_leaf) {
-            uint32_t next = cur + 1u - (1u << 27);  // first+1, count-1
-            uint32_t popped = stk.pop_if(last, top);
-            cur = last ? popped : next;
+            const bool last_now = left == more;
+            uint32_t next = cur + (more + 1u) - ((more + 1u) << 27);  // first+1, count-1 per test
+            uint32_t popped = stk.pop_if(last_now, top);
+            cur = last_now ? popped : next;
           }
           n_leaf = wave_count((int)cur < -1);
         } while (n_leaf > 0 && 2 * n_leaf > n_trav);
