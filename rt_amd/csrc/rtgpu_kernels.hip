@@ -664,9 +664,9 @@ void trace_kernel(const KParams P) {
     // ---- (4) closest hit: ordered stack traversal (rows a3-a5) ------------------
     // Every lane walks its own ray in the oracle's order; what the WAVE executes
     // next is put to a vote between the lanes waiting at an inner node and the
-    // lanes waiting at a leaf: the majority's step kind runs, and keeps running
-    // while it stays the majority (one popcount per step), the other lanes sit
-    // those steps out.  A plain while-while loop ran the node step for as few as
+    // lanes waiting at a leaf: the node step runs while two thirds of the lanes
+    // wait for it, the leaf step otherwise (one popcount per step; measured best
+    // of 1/3, 2/5, 1/2, 3/5, 2/3, 3/4, 4/5, 7/8), the other lanes sit those steps out.  A plain while-while loop ran the node step for as few as
     // one lane (measured 13-27 % lane utilisation in the node step).
     // A leaf step tests ONE primitive and advances the reference in place
     // (first+1, count-1), so lanes with short leaves never wait for long ones.
@@ -681,7 +681,7 @@ void trace_kernel(const KParams P) {
       int n_node = wave_count((int)cur >= 0);
       if (STATS == 2) { wave_tick(lane, w_trav); if ((int)cur != -1) l_trav++; }
       long long c_phase = STATS == 2 ? (long long)clock64() : 0;
-      if (2 * n_node >= n_trav) {
+      if (3 * n_node >= 2 * n_trav) {
         do {
           if (WIDE && (int)cur >= 0) {
             if (STATS == 2) wave_tick(lane, w_node);
@@ -802,7 +802,7 @@ void trace_kernel(const KParams P) {
             cur = stk.step(h0 && h1, !(h0 || h1), near_c, far_c, top);
           }
           n_node = wave_count((int)cur >= 0);
-        } while (n_node > 0 && 2 * n_node >= n_trav);
+        } while (n_node > 0 && 3 * n_node >= 2 * n_trav);
         if (STATS == 2) c_nodes += (long long)clock64() - c_phase;
       } else {
         int n_leaf;
@@ -876,7 +876,7 @@ void trace_kernel(const KParams P) {
             cur = last_now ? popped : next;
           }
           n_leaf = wave_count((int)cur < -1);
-        } while (n_leaf > 0 && 2 * n_leaf > n_trav);
+        } while (n_leaf > 0 && 3 * n_leaf > n_trav);
         if (STATS == 2) c_leaves += (long long)clock64() - c_phase;
       }
     }
