@@ -4,7 +4,7 @@
 A "step" is one pass of the trace loop over one frame of the default scene S0
 (SURVEY.md §8d).  At N=1 the workload is BASELINE.json configs[1] ("C2"):
 S0, 1920x1080, 16 spp, depth 8, one MI355X.  At N>1 the frame is split into
-64x64 tiles interleaved over the ranks (one process per GPU), every rank traces
+16x16 tiles interleaved over the ranks (one process per GPU), every rank traces
 its tiles from a replicated scene, RCCL gathers the compact tile buffers to
 rank 0 and rank 0 de-interleaves them; the per-GPU work is held fixed (weak
 scaling) by tracing 16*N spp, so a step at N GPUs is a 16N-spp frame.
@@ -130,7 +130,10 @@ def main():
 
     W, H, depth = args.width, args.height, args.depth
     spp = args.spp * world
-    tile = 64
+    # 16x16 tiles: the slowest of 8 ranks is then 0.8 % above the mean (64x64: 4.2 %, 32x32:
+    # 1.3 %; tools/gpu_rank_balance.py), and every rank owns the same number of tiles.  The
+    # image does not depend on the tile size.
+    tile = 16
     ctx = ra.Context(local_rank)
     scene, cam = ra.Scene.builtin(0, aspect=W / H)
     ctx.upload(scene)
@@ -213,7 +216,7 @@ def main():
             "config": {
                 "workload": f"C2: procedural scene S0 (RTIOW cover, {scene.n_prims} prims), "
                             f"{W}x{H}, {args.spp} spp per GPU ({spp} spp total), depth {depth}, "
-                            f"pinhole, 64x64 tiles interleaved over {world} GPU(s)"
+                            f"pinhole, {tile}x{tile} tiles interleaved over {world} GPU(s)"
                             + (", RCCL gather to rank 0" if compact and not share_gpu else "")
                             + (" [REHEARSAL: all ranks on one GPU, gloo gather via host]" if share_gpu else ""),
                 "rays_per_step": int(rays_per_step), "paths_per_step": W * H * spp,
