@@ -220,3 +220,15 @@ rtgpu_node4 *collapse_nodes4(const rtgpu_node *nodes, uint64_t n, uint64_t *n_ou
 }
 
 }  // namespace rtgpu
+
+// Test hook: node count and stack bound of the host collapse of a BVH2 (what the device
+// collapse of collapse4.hip must reproduce; its numbering differs).  0 on success.
+extern "C" int rtgpu_debug_collapse4_counts(const void *nodes, uint64_t n, uint64_t *n4, uint32_t *max_stack) {
+  std::string err;
+  uint32_t *src = nullptr;
+  rtgpu_node4 *p = rtgpu::collapse_nodes4((const rtgpu_node *)nodes, n, n4, max_stack, &src, err);
+  if (!p) return 1;
+  std::free(p);
+  std::free(src);
+  return 0;
+}

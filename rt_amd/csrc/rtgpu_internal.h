@@ -21,6 +21,15 @@ rtgpu_node48 *pack_nodes48(const rtgpu_node *nodes, uint64_t n, std::string &err
 // bvh4_build.cpp: 64-byte BVH2 nodes -> four-wide packed nodes (malloc'ed; NULL + err on failure)
 rtgpu_node4 *collapse_nodes4(const rtgpu_node *nodes, uint64_t n, uint64_t *n_out, uint32_t *max_stack,
                              uint32_t **src_out, std::string &err);
+// collapse4.hip: the same collapse on the device (numbering breadth first); exact-size hipMalloc'ed arrays
+struct Nodes4Device {
+  void *d_nodes4 = nullptr, *d_src = nullptr;
+  uint64_t n_nodes4 = 0;
+  uint32_t max_stack4 = 0;
+  double gpu_ms = 0.0;
+};
+int  collapse_nodes4_device(const void *d_nodes, uint64_t n_nodes, Nodes4Device *out, std::string &err);
+void free_nodes4_device(Nodes4Device *out);
 // pack48.hip: four-wide nodes re-read from refitted 64-byte nodes through their source map, on the device
 int  refresh_nodes4_device(const void *d_nodes, void *d_nodes4, const void *d_src, uint64_t n4, uint32_t *d_flag,
                            std::string &err);

@@ -108,3 +108,46 @@ def test_lbvh_upload_rejects_bad_input(ra, gpu_ctx):
     nan = make_scene(ra, triangles=[((float("nan"), 0, 0), (1, 0, 0), (0, 1, 0), 0)], materials=[(0, .5, .5, .5, 0)])
     with pytest.raises(ra.RtgpuError):
         gpu_ctx.upload(nan, builder="lbvh")
+
+
+@pytest.mark.gpu
+def test_four_wide_nodes_collapsed_on_the_gpu(ra, oracle, gpu_ctx):
+    """collapse4.hip: the four-wide nodes of a GPU-built tree are made on the GPU.  They must
+    be a valid tree over the same primitives (validator of the restatement), have the node
+    count and stack bound of the host's collapse of the same BVH2 (same rule, other
+    numbering), and every node must hold the boxes its source map names."""
+    ra.lib.rtgpu_debug_collapse4_counts.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
+    for kind, param in ((1, 5), (2, 4), (1, 6)):
+        scene, cam = ra.Scene.builtin(kind, param=param, aspect=16 / 9)
+        gpu_ctx.upload(scene, builder="lbvh")
+        fs = gpu_ctx.flat_scene()
+        assert fs.c.n_nodes >= ra.NODE48_MIN_NODES and fs.c.nodes4 and fs.c.nodes4_src
+        rc, _ = oracle.validate_bvh(fs.c)
+        assert rc == 0, f"validator code {rc}"
+        n4, ms = C.c_uint64(), C.c_uint32()
+        assert ra.lib.rtgpu_debug_collapse4_counts(fs.c.nodes, fs.c.n_nodes, C.byref(n4), C.byref(ms)) == 0
+        assert (fs.c.n_nodes4, fs.c.max_stack4) == (n4.value, ms.value)
+        # boxes: child k of node i = the box (node2, slot) of the BVH2 its source word names, moved
+        # by less than 512 floats to carry the reference bytes; missing children have no source
+        nodes = fs.nodes_u32.reshape(-1, 16)
+        w4 = fs.nodes4_u32.reshape(-1, 4, 6)
+        src = fs.nodes4_src.reshape(-1, 4)
+        have = src != 0xFFFFFFFF
+        boxes2 = nodes[:, :12].reshape(-1, 2, 6)                       # lo0 hi0 | lo1 hi1
+        want = boxes2[src[have] >> 1, src[have] & 1]
+        got = w4[have]
+        key = lambda u: np.where(u & 0x80000000, ~u, u | 0x80000000).astype(np.int64)   # ordered float bits
+        d = key(got) - key(want)
+        assert np.abs(d).max() < 512
+        assert (d[:, :3] <= 0).all() and (d[:, 3:] >= 0).all()          # lo planes down, hi planes up
+        refs = (w4[..., 0] & 0xFF) | ((w4[..., 1] & 0xFF) << 8) | ((w4[..., 2] & 0xFF) << 16) | ((w4[..., 3] & 0xFF) << 24)
+        assert (refs[~have] == 0xFFFFFFFF).all()
+        # every inner reference names a later node, each exactly once (breadth-first numbering)
+        inner = refs[have & ((refs & 0x80000000) == 0)]
+        assert np.array_equal(np.sort(inner), np.arange(1, fs.c.n_nodes4))
+        # and the frame through them is the oracle's, counters included
+        st = ra.default_settings(96, 54, spp=2, max_depth=6, flags=ra.FLAG_STATS)
+        acc, ids, stats = gpu_ctx.render(cam, st)
+        want_acc, want_ids, want_stats = oracle.render(fs.c, cam, st, threads=4)
+        assert np.array_equal(ids, want_ids) and np.array_equal(bits(acc), bits(want_acc))
+        assert stats.as_dict() == want_stats
