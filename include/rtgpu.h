@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define RTGPU_ABI_VERSION 3u
+#define RTGPU_ABI_VERSION 4u
 
 /* ---- scene description (host side, caller-owned) ------------------------ */
 
@@ -184,9 +184,20 @@ int  rtgpu_upload_scene(rtgpu_ctx *ctx, const rtgpu_scene_desc *scene);
  * hierarchy (HPG 2012), level-by-level box fit - straight into the same
  * flattened format, one primitive per leaf.  Builds in milliseconds where the
  * host SAH build takes seconds, for a tree that costs more node visits per ray;
- * meant for scenes that change.  rtgpu_get_flat_scene returns a host copy
- * (build_ms = GPU time of the build). */
+ * meant for scenes that change.  The packed copy and the four-wide nodes of the tree
+ * are made on the GPU too; rtgpu_get_flat_scene copies the result back when it is
+ * first asked for (build_ms = GPU time of the build). */
 int  rtgpu_upload_scene_lbvh(rtgpu_ctx *ctx, const rtgpu_scene_desc *scene);
+/* rtgpu_upload_scene_lbvh for primitives that already live in the memory of the
+ * context's GPU (a simulation, a skinning pass or a loader wrote them there):
+ * arrays of rtgpu_sphere / rtgpu_triangle (either may be NULL with a count of 0),
+ * only read; the material table comes from the host.  Nothing else crosses PCIe
+ * and the input check runs on the GPU.  Replaces the uploaded scene; counts and
+ * topology are free, so this is what a frame loop calls when rtgpu_refit_device's
+ * fixed tree no longer fits.  No reference counterpart. */
+int  rtgpu_build_device(rtgpu_ctx *ctx, const void *d_spheres, uint64_t n_spheres,
+                        const void *d_triangles, uint64_t n_triangles,
+                        const rtgpu_material *materials, uint64_t n_materials);
 /* New positions (and material table) under the UNCHANGED tree of the uploaded
  * scene: `scene` must hold the same number of spheres, triangles and materials,
  * primitive i being the moved / edited primitive i.  Leaf records and every box

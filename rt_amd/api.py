@@ -162,6 +162,7 @@ lib.rtgpu_scene_builtin.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, _P(Scene
 lib.rtgpu_upload_scene_lbvh.argtypes = [C.c_void_p, _P(SceneDesc)]
 lib.rtgpu_refit.argtypes = [C.c_void_p, _P(SceneDesc)]
 lib.rtgpu_refit_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
+lib.rtgpu_build_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
 lib.rtgpu_scene_free.argtypes = [_P(SceneDesc)]
 lib.rtgpu_scene_free.restype = None
 lib.rtgpu_scene_parse_obj.argtypes = [C.c_char_p, C.c_uint64, _P(SceneDesc)]
@@ -372,6 +373,13 @@ class Context:
         """rtgpu_refit_device: the moved primitives as device arrays (SPHERE_DTYPE /
         TRIANGLE_DTYPE records, e.g. the data_ptr() of a torch uint8 tensor)."""
         self._check(lib.rtgpu_refit_device(self._h, spheres_ptr, n_spheres, triangles_ptr, n_triangles))
+
+    def build_device(self, spheres_ptr, n_spheres, triangles_ptr, n_triangles, materials):
+        """rtgpu_build_device: LBVH over primitive arrays in device memory (SPHERE_DTYPE /
+        TRIANGLE_DTYPE records); `materials`: numpy array of MATERIAL_DTYPE on the host."""
+        mats = np.ascontiguousarray(materials, dtype=MATERIAL_DTYPE)
+        self._check(lib.rtgpu_build_device(self._h, spheres_ptr, n_spheres, triangles_ptr, n_triangles,
+                                           mats.ctypes.data, len(mats)))
 
     def flat_scene(self):
         fs = FlatSceneC()

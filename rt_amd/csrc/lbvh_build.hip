@@ -339,7 +339,16 @@ void free_lbvh(LbvhDevice *out) {
 // The current device must be the context's.  The scene must have passed
 // validate_scene.  Output arrays carry the zeroed tail records flatten_scene adds.
 int lbvh_build_device(const rtgpu_scene_desc *scene, LbvhDevice *out, std::string &err) {
+  return lbvh_build_device_ptrs(scene, nullptr, nullptr, out, err);
+}
+
+// The same with the primitive arrays already in device memory when d_spheres_in /
+// d_triangles_in are given (scene->spheres / ->triangles are then not read; the counts
+// are).  The arrays must have passed check_prims_device.
+int lbvh_build_device_ptrs(const rtgpu_scene_desc *scene, const void *d_spheres_in, const void *d_triangles_in,
+                           LbvhDevice *out, std::string &err) {
   std::memset(out, 0, sizeof(*out));
+  const bool on_device = d_spheres_in || d_triangles_in;
   const uint64_t ns64 = scene->n_spheres, nt64 = scene->n_triangles, P64 = ns64 + nt64;
   if (P64 >= (1ull << 28)) { err = "lbvh: too many primitives (limit 2^28)"; return 1; }
   const uint32_t ns = (uint32_t)ns64, nt = (uint32_t)nt64, P = (uint32_t)P64;
@@ -366,8 +375,12 @@ int lbvh_build_device(const rtgpu_scene_desc *scene, LbvhDevice *out, std::strin
     root.child0 = root.child1 = RTGPU_REF_EMPTY;
     if (P == 1) {
       float lo[3], hi[3];
+      rtgpu_sphere s1;
+      rtgpu_triangle t1;
+      if (on_device && ns) LB_TRY(hipMemcpy(&s1, d_spheres_in, sizeof(s1), hipMemcpyDeviceToHost));
+      if (on_device && nt) LB_TRY(hipMemcpy(&t1, d_triangles_in, sizeof(t1), hipMemcpyDeviceToHost));
       if (ns) {
-        const rtgpu_sphere &s = scene->spheres[0];
+        const rtgpu_sphere &s = on_device ? s1 : scene->spheres[0];
         for (int k = 0; k < 3; k++) { lo[k] = s.center[k] - s.radius; hi[k] = s.center[k] + s.radius; }
         rtgpu_sph r = {{s.center[0], s.center[1], s.center[2]}, s.radius};
         uint32_t meta[2] = {0u, s.material};
@@ -375,7 +388,7 @@ int lbvh_build_device(const rtgpu_scene_desc *scene, LbvhDevice *out, std::strin
         LB_TRY(hipMemcpy(out->d_sph_meta, meta, sizeof(meta), hipMemcpyHostToDevice));
         root.child0 = RTGPU_REF_LEAF | RTGPU_REF_SPHERE;
       } else {
-        const rtgpu_triangle &t = scene->triangles[0];
+        const rtgpu_triangle &t = on_device ? t1 : scene->triangles[0];
         rtgpu_tri r;
         std::memset(&r, 0, sizeof(r));
         for (int k = 0; k < 3; k++) {
@@ -406,8 +419,13 @@ int lbvh_build_device(const rtgpu_scene_desc *scene, LbvhDevice *out, std::strin
            *d_height = nullptr, *d_done = nullptr, *d_count = nullptr, *d_list_a = nullptr, *d_list_b = nullptr;
   unsigned long long *d_keys_a = nullptr, *d_keys_b = nullptr;
   int *d_c0 = nullptr, *d_c1 = nullptr;
-  LB_TRY(tmp.alloc(&d_sph_in, ns));
-  LB_TRY(tmp.alloc(&d_tri_in, nt));
+  if (on_device) {  // read in place
+    d_sph_in = (rtgpu_sphere *)d_spheres_in;
+    d_tri_in = (rtgpu_triangle *)d_triangles_in;
+  } else {
+    LB_TRY(tmp.alloc(&d_sph_in, ns));
+    LB_TRY(tmp.alloc(&d_tri_in, nt));
+  }
   LB_TRY(tmp.alloc(&d_pbox, P));
   LB_TRY(tmp.alloc(&d_nbox, (size_t)n_inner));
   LB_TRY(tmp.alloc(&d_cent, (size_t)P * 3));
@@ -433,8 +451,8 @@ int lbvh_build_device(const rtgpu_scene_desc *scene, LbvhDevice *out, std::strin
   size_t tmp_bytes = sort_bytes > scan_bytes ? sort_bytes : scan_bytes;
   LB_TRY(tmp.alloc(&d_tmp, tmp_bytes));
 
-  if (ns) LB_TRY(hipMemcpy(d_sph_in, scene->spheres, (size_t)ns * sizeof(rtgpu_sphere), hipMemcpyHostToDevice));
-  if (nt) LB_TRY(hipMemcpy(d_tri_in, scene->triangles, (size_t)nt * sizeof(rtgpu_triangle), hipMemcpyHostToDevice));
+  if (ns && !on_device) LB_TRY(hipMemcpy(d_sph_in, scene->spheres, (size_t)ns * sizeof(rtgpu_sphere), hipMemcpyHostToDevice));
+  if (nt && !on_device) LB_TRY(hipMemcpy(d_tri_in, scene->triangles, (size_t)nt * sizeof(rtgpu_triangle), hipMemcpyHostToDevice));
   const uint32_t cb_init[8] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u};
   LB_TRY(hipMemcpy(d_cb, cb_init, sizeof(cb_init), hipMemcpyHostToDevice));
   LB_TRY(hipMemset(d_done, 0, (size_t)n_inner * sizeof(uint32_t)));

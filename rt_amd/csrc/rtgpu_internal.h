@@ -44,6 +44,9 @@ struct LbvhDevice {
   double gpu_ms;  // first kernel to last, HIP events
 };
 int  lbvh_build_device(const rtgpu_scene_desc *scene, LbvhDevice *out, std::string &err);
+// the same over rtgpu_sphere / rtgpu_triangle arrays in device memory (scene gives the counts only)
+int  lbvh_build_device_ptrs(const rtgpu_scene_desc *scene, const void *d_spheres, const void *d_triangles,
+                            LbvhDevice *out, std::string &err);
 void free_lbvh(LbvhDevice *out);
 
 // refit.hip: new geometry under the uploaded tree's topology, in place on the device arrays

@@ -1257,9 +1257,11 @@ extern "C" int rtgpu_upload_scene(rtgpu_ctx *ctx, const rtgpu_scene_desc *scene)
   return 0;
 }
 
-// As rtgpu_upload_scene, with the BVH built on the GPU (lbvh_build.hip).  The
-// flattened scene is also copied back to the host so that rtgpu_get_flat_scene
-// (and with it the oracle) sees exactly what the kernels traverse.
+namespace {
+int upload_lbvh_common(rtgpu_ctx *ctx, const rtgpu_scene_desc *scene, const void *d_spheres, const void *d_triangles);
+}
+
+// As rtgpu_upload_scene, with the BVH built on the GPU (lbvh_build.hip).
 extern "C" int rtgpu_upload_scene_lbvh(rtgpu_ctx *ctx, const rtgpu_scene_desc *scene) {
   if (!ctx) return 1;
   if (ctx->pending) { ctx->err = "a frame begun with rtgpu_render_begin is pending (call rtgpu_render_end)"; return 1; }
@@ -1267,8 +1269,41 @@ extern "C" int rtgpu_upload_scene_lbvh(rtgpu_ctx *ctx, const rtgpu_scene_desc *s
   HIP_TRY(ctx, hipDeviceSynchronize());
   free_scene_device(ctx);
   if (rtgpu::validate_scene(scene, ctx->err)) return 1;
+  return upload_lbvh_common(ctx, scene, nullptr, nullptr);
+}
+
+// The same for primitives that already live in GPU memory (a simulation or a loader wrote
+// them there): rtgpu_sphere / rtgpu_triangle arrays on the context's device, the material
+// table from the host.  Nothing but the materials crosses PCIe; the arrays are only read.
+extern "C" int rtgpu_build_device(rtgpu_ctx *ctx, const void *d_spheres, uint64_t n_spheres, const void *d_triangles,
+                                  uint64_t n_triangles, const rtgpu_material *materials, uint64_t n_materials) {
+  if (!ctx) return 1;
+  if (ctx->pending) { ctx->err = "a frame begun with rtgpu_render_begin is pending (call rtgpu_render_end)"; return 1; }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  free_scene_device(ctx);
+  if ((n_spheres && !d_spheres) || (n_triangles && !d_triangles)) { ctx->err = "NULL device array with a non-zero count"; return 1; }
+  if (n_spheres + n_triangles >= (1ull << 28)) { ctx->err = "lbvh: too many primitives (limit 2^28)"; return 1; }
+  rtgpu_scene_desc scene;
+  std::memset(&scene, 0, sizeof(scene));
+  scene.materials = materials;
+  scene.n_materials = n_materials;
+  if (rtgpu::validate_scene(&scene, ctx->err)) return 1;  // the material table
+  // what validate_scene checks for primitives on the host, on the device
+  if (int rc = rtgpu::check_prims_device(d_spheres, (uint32_t)n_spheres, d_triangles, (uint32_t)n_triangles,
+                                         (uint32_t)std::min<uint64_t>(n_materials, 0xFFFFFFFFull), nullptr, ctx->err))
+    return rc;
+  scene.n_spheres = n_spheres;
+  scene.n_triangles = n_triangles;
+  return upload_lbvh_common(ctx, &scene, n_spheres ? d_spheres : nullptr, n_triangles ? d_triangles : nullptr);
+}
+
+namespace {
+// scene: validated; its primitive arrays are read from d_spheres / d_triangles when given
+int upload_lbvh_common(rtgpu_ctx *ctx, const rtgpu_scene_desc *scene, const void *d_spheres, const void *d_triangles) {
   rtgpu::LbvhDevice L;
-  int rc = rtgpu::lbvh_build_device(scene, &L, ctx->err);
+  int rc = (d_spheres || d_triangles) ? rtgpu::lbvh_build_device_ptrs(scene, d_spheres, d_triangles, &L, ctx->err)
+                                      : rtgpu::lbvh_build_device(scene, &L, ctx->err);
   if (rc) return rc;
   ctx->d_nodes = L.d_nodes; ctx->d_tris = L.d_tris; ctx->d_sphs = L.d_sphs; ctx->d_sph_meta = L.d_sph_meta;
   // The host copy of the flattened scene (what rtgpu_get_flat_scene hands out) is made on
@@ -1322,6 +1357,7 @@ extern "C" int rtgpu_upload_scene_lbvh(rtgpu_ctx *ctx, const rtgpu_scene_desc *s
   ctx->have_scene = true;
   return 0;
 }
+}  // namespace
 
 // New geometry (and material table) under the topology of the uploaded tree
 // (refit.hip).  The host copy of the flattened scene is refreshed lazily, by the

@@ -46,6 +46,13 @@ void rt_scene_refit_device_or_panic(Sphere const *d_spheres, s64 spheres_count, 
     errf("rt: scene refit failed: %s", ::rtgpu_last_error(gRt_Ctx));
 }
 
+void rt_scene_build_device_or_panic(Sphere const *d_spheres, s64 spheres_count, Triangle const *d_triangles,
+                                    s64 triangles_count, Material const *materials, s64 materials_count) {
+  if (::rtgpu_build_device(gRt_Ctx, d_spheres, (uint64_t)spheres_count, d_triangles, (uint64_t)triangles_count,
+                           (::rtgpu_material const *)materials, (uint64_t)materials_count) != 0)
+    errf("rt: scene build failed: %s", ::rtgpu_last_error(gRt_Ctx));
+}
+
 Camera rt_camera_look_at(Vec3 from, Vec3 at, Vec3 up, f32 vfov_deg, f32 aspect, f32 aperture,
                          f32 focus_dist) {
   Camera cam;

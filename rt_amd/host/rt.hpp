@@ -84,6 +84,10 @@ void rt_scene_refit_or_panic(Scene const &scene);
 // the same with the moved spheres / triangles already in GPU memory (device pointers)
 void rt_scene_refit_device_or_panic(Sphere const *d_spheres, s64 spheres_count, Triangle const *d_triangles,
                                     s64 triangles_count);
+// A new tree (GPU-built LBVH) over spheres / triangles that already live in GPU memory
+// (device pointers; counts and topology are free); the materials come from the host.
+void rt_scene_build_device_or_panic(Sphere const *d_spheres, s64 spheres_count, Triangle const *d_triangles,
+                                    s64 triangles_count, Material const *materials, s64 materials_count);
 
 [[nodiscard]] Camera rt_camera_look_at(Vec3 from, Vec3 at, Vec3 up, f32 vfov_deg, f32 aspect,
                                        f32 aperture = 0.f, f32 focus_dist = 10.f);

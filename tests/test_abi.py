@@ -17,13 +17,13 @@ def declared_functions():
 
 def test_every_declared_symbol_is_exported(ra):
     names = declared_functions()
-    assert len(names) >= 19, names
+    assert len(names) >= 20, names
     for n in names:
         assert hasattr(ra.lib, n), f"librtgpu.so does not export {n}"
 
 
 def test_abi_version_and_struct_sizes(ra):
-    assert ra.lib.rtgpu_abi_version() == 3
+    assert ra.lib.rtgpu_abi_version() == 4
     from rt_amd import api
     assert C.sizeof(api.Camera) == 80
     assert C.sizeof(api.Settings) == 72

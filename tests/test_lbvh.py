@@ -151,3 +151,58 @@ def test_four_wide_nodes_collapsed_on_the_gpu(ra, oracle, gpu_ctx):
         want_acc, want_ids, want_stats = oracle.render(fs.c, cam, st, threads=4)
         assert np.array_equal(ids, want_ids) and np.array_equal(bits(acc), bits(want_acc))
         assert stats.as_dict() == want_stats
+
+
+@pytest.mark.gpu
+def test_build_from_device_arrays(ra, oracle, gpu_ctx):
+    """rtgpu_build_device: the tree over primitive arrays in GPU memory is byte for byte the
+    tree rtgpu_upload_scene_lbvh builds from the same arrays on the host; bad input is found
+    on the GPU; counts may change from one build to the next."""
+    import torch
+    for name in ("random mixed", "S1 level 5 (20k tris)", "one triangle", "one sphere", "two", "empty"):
+        scene = _scenes(ra)[name]
+        gpu_ctx.upload(scene, builder="lbvh")
+        want_fs = gpu_ctx.flat_scene()
+        want = _flat_bytes(want_fs.c)
+        want_counts = (want_fs.c.n_nodes, want_fs.c.max_depth, want_fs.c.n_nodes4, want_fs.c.max_stack4)
+        d_sph = torch.from_numpy(scene.spheres.view(np.uint8).copy()).cuda() if len(scene.spheres) else None
+        d_tri = torch.from_numpy(scene.triangles.view(np.uint8).copy()).cuda() if len(scene.triangles) else None
+        gpu_ctx.build_device(d_sph.data_ptr() if d_sph is not None else None, len(scene.spheres),
+                             d_tri.data_ptr() if d_tri is not None else None, len(scene.triangles), scene.materials)
+        got_fs = gpu_ctx.flat_scene()
+        got = _flat_bytes(got_fs.c)
+        for k in want:
+            assert got[k] == want[k], f"{name}: {k} differ"
+        assert (got_fs.c.n_nodes, got_fs.c.max_depth, got_fs.c.n_nodes4, got_fs.c.max_stack4) == want_counts, name
+        rc, _ = oracle.validate_bvh(got_fs.c)
+        assert rc == 0, f"{name}: validator code {rc}"
+    # a frame through a device-built tree, then a rebuild with other counts
+    scene, cam = ra.Scene.builtin(1, param=5, aspect=16 / 9)
+    d_tri = torch.from_numpy(scene.triangles.view(np.uint8).copy()).cuda()
+    gpu_ctx.build_device(None, 0, d_tri.data_ptr(), len(scene.triangles), scene.materials)
+    st = ra.default_settings(96, 54, spp=2, max_depth=6, flags=ra.FLAG_STATS)
+    acc, ids, stats = gpu_ctx.render(cam, st)
+    w_acc, w_ids, w_stats = oracle.render(gpu_ctx.flat_scene().c, cam, st, threads=4)
+    assert np.array_equal(ids, w_ids) and np.array_equal(bits(acc), bits(w_acc)) and stats.as_dict() == w_stats
+    half = len(scene.triangles) // 2
+    gpu_ctx.build_device(None, 0, d_tri.data_ptr(), half, scene.materials)
+    assert gpu_ctx.flat_scene().c.n_tris == half
+    acc2, ids2, _ = gpu_ctx.render(cam, st)
+    w_acc2, w_ids2, _ = oracle.render(gpu_ctx.flat_scene().c, cam, st, threads=4)
+    assert np.array_equal(ids2, w_ids2) and np.array_equal(bits(acc2), bits(w_acc2))
+    assert ids2[ids2 != 0xFFFFFFFF].max() < half
+    # bad input: found on the GPU, nothing uploaded
+    bad = scene.triangles.copy()
+    bad["v2"][11, 0] = np.nan
+    d_bad = torch.from_numpy(bad.view(np.uint8).copy()).cuda()
+    with pytest.raises(ra.RtgpuError, match="non-finite"):
+        gpu_ctx.build_device(None, 0, d_bad.data_ptr(), len(bad), scene.materials)
+    bad = scene.triangles.copy()
+    bad["material"][5] = len(scene.materials)
+    d_bad = torch.from_numpy(bad.view(np.uint8).copy()).cuda()
+    with pytest.raises(ra.RtgpuError):
+        gpu_ctx.build_device(None, 0, d_bad.data_ptr(), len(bad), scene.materials)
+    with pytest.raises(ra.RtgpuError, match="NULL"):
+        gpu_ctx.build_device(None, 3, None, 0, scene.materials)
+    with pytest.raises(ra.RtgpuError, match="no scene"):
+        gpu_ctx.render(cam, st)

@@ -1,7 +1,8 @@
 """A dynamic scene end to end on the GPU: every frame a torch kernel moves the vertices of
 S2 (level 8: 10.5 M triangles) in place, rtgpu_refit_device refits the uploaded tree from
-those device arrays, and the frame is traced - nothing crosses PCIe.  Prints ms per frame
-and the share of each part.  usage: gpu_animation.py [level] [frames]"""
+those device arrays (or, second pass, rtgpu_build_device builds a NEW tree over them), and
+the frame is traced - nothing crosses PCIe.  Prints ms per frame and the share of each
+part.  usage: gpu_animation.py [level] [frames]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -21,24 +22,28 @@ rest = torch.from_numpy(scene.triangles.view(np.float32).reshape(-1, 10).copy())
 cur = rest.clone()
 n_tri = len(scene.triangles)
 torch.cuda.synchronize()
-t_move = t_refit = t_trace = 0.0
-for f in range(frames + 2):
-    if f == 2:
-        t_move = t_refit = t_trace = 0.0
-    a = time.perf_counter()
-    phase = 0.3 * f
-    for v in range(3):  # y += 0.02 * sin(3 x + phase) per vertex
-        cur[:, 3 * v + 1] = rest[:, 3 * v + 1] + 0.02 * torch.sin(3.0 * rest[:, 3 * v] + phase)
-    torch.cuda.synchronize()
-    b = time.perf_counter()
-    ctx.refit_device(None, 0, cur.data_ptr(), n_tri)
-    c = time.perf_counter()
-    ctx.render_device(cam, st, accum.data_ptr())
-    torch.cuda.synchronize()
-    d = time.perf_counter()
-    t_move += b - a; t_refit += c - b; t_trace += d - c
-per = (t_move + t_refit + t_trace) / frames * 1e3
-print(f"S2 level {level}: {n_tri} triangles, upload {t_up * 1e3:.0f} ms; {frames} animated frames at 1080p 4 spp: "
-      f"{per:.2f} ms per frame = move {t_move / frames * 1e3:.2f} + refit {t_refit / frames * 1e3:.2f} + trace {t_trace / frames * 1e3:.2f}",
-      flush=True)
+for mode in ("refit", "rebuild"):
+    t_move = t_refit = t_trace = 0.0
+    for f in range(frames + 2):
+        if f == 2:
+            t_move = t_refit = t_trace = 0.0
+        a = time.perf_counter()
+        phase = 0.3 * f
+        for v in range(3):  # y += 0.02 * sin(3 x + phase) per vertex
+            cur[:, 3 * v + 1] = rest[:, 3 * v + 1] + 0.02 * torch.sin(3.0 * rest[:, 3 * v] + phase)
+        torch.cuda.synchronize()
+        b = time.perf_counter()
+        if mode == "refit":
+            ctx.refit_device(None, 0, cur.data_ptr(), n_tri)
+        else:
+            ctx.build_device(None, 0, cur.data_ptr(), n_tri, scene.materials)
+        c = time.perf_counter()
+        ctx.render_device(cam, st, accum.data_ptr())
+        torch.cuda.synchronize()
+        d = time.perf_counter()
+        t_move += b - a; t_refit += c - b; t_trace += d - c
+    per = (t_move + t_refit + t_trace) / frames * 1e3
+    print(f"S2 level {level}: {n_tri} triangles, upload {t_up * 1e3:.0f} ms; {frames} animated frames at 1080p 4 spp, {mode} every frame: "
+          f"{per:.2f} ms per frame = move {t_move / frames * 1e3:.2f} + {mode} {t_refit / frames * 1e3:.2f} + trace {t_trace / frames * 1e3:.2f}",
+          flush=True)
 ctx.close()
