@@ -194,7 +194,9 @@ int  rtgpu_upload_scene_lbvh(rtgpu_ctx *ctx, const rtgpu_scene_desc *scene);
  * only read; the material table comes from the host.  Nothing else crosses PCIe
  * and the input check runs on the GPU.  Replaces the uploaded scene; counts and
  * topology are free, so this is what a frame loop calls when rtgpu_refit_device's
- * fixed tree no longer fits.  No reference counterpart. */
+ * fixed tree no longer fits.  The context keeps the builder's temporaries between
+ * such calls (rtgpu_upload_scene* and rtgpu_destroy release them).  No reference
+ * counterpart. */
 int  rtgpu_build_device(rtgpu_ctx *ctx, const void *d_spheres, uint64_t n_spheres,
                         const void *d_triangles, uint64_t n_triangles,
                         const rtgpu_material *materials, uint64_t n_materials);

@@ -13,6 +13,7 @@
 
 #include <string>
 
+#include "dev_pool.h"
 #include "pack48.h"
 #include "rtgpu_internal.h"
 
@@ -139,10 +140,10 @@ __global__ __launch_bounds__(256) void collapse_level(const rtgpu_node *nodes, u
 
 namespace rtgpu {
 
-void free_nodes4_device(Nodes4Device *out) {
+void free_nodes4_device(Nodes4Device *out, DevPool *pool) {
   if (!out) return;
-  (void)hipFree(out->d_nodes4);
-  (void)hipFree(out->d_src);
+  dev_put(pool, out->d_nodes4);
+  dev_put(pool, out->d_src);
   *out = Nodes4Device{};
 }
 
@@ -151,15 +152,15 @@ void free_nodes4_device(Nodes4Device *out) {
     hipError_t e_ = (call);                                                 \
     if (e_ != hipSuccess) {                                                 \
       err = std::string("four-wide nodes: " #call ": ") + hipGetErrorString(e_); \
-      (void)hipFree(d_pend); (void)hipFree(d_tmp4); (void)hipFree(d_tmps); (void)hipFree(d_cnt); \
-      free_nodes4_device(out);                                              \
+      dev_put(pool, d_pend); dev_put(pool, d_tmp4); dev_put(pool, d_tmps); dev_put(pool, d_cnt); \
+      free_nodes4_device(out, pool);                                        \
       return 2;                                                             \
     }                                                                       \
   } while (0)
 
 // The current device must be the context's.  Synchronous.  On success out->d_nodes4 and
 // out->d_src are exact-size device arrays (hipMalloc) the caller owns.
-int collapse_nodes4_device(const void *d_nodes, uint64_t n_nodes, Nodes4Device *out, std::string &err) {
+int collapse_nodes4_device(const void *d_nodes, uint64_t n_nodes, DevPool *pool, Nodes4Device *out, std::string &err) {
   *out = Nodes4Device{};
   Pend *d_pend = nullptr;
   rtgpu_node4 *d_tmp4 = nullptr;
@@ -168,10 +169,10 @@ int collapse_nodes4_device(const void *d_nodes, uint64_t n_nodes, Nodes4Device *
   if (n_nodes == 0 || n_nodes >= (1ull << 31)) { err = fail; return 1; }
   // a four-wide node consumes at least one BVH2 node: n_nodes bounds their number
   const uint32_t cap = (uint32_t)n_nodes;
-  C4_TRY(hipMalloc((void **)&d_pend, (size_t)cap * sizeof(Pend)));
-  C4_TRY(hipMalloc((void **)&d_tmp4, (size_t)cap * sizeof(rtgpu_node4)));
-  C4_TRY(hipMalloc((void **)&d_tmps, (size_t)cap * 16));
-  C4_TRY(hipMalloc((void **)&d_cnt, 4 * sizeof(uint32_t)));
+  C4_TRY(dev_get(pool, (void **)&d_pend, (size_t)cap * sizeof(Pend)));
+  C4_TRY(dev_get(pool, (void **)&d_tmp4, (size_t)cap * sizeof(rtgpu_node4)));
+  C4_TRY(dev_get(pool, (void **)&d_tmps, (size_t)cap * 16));
+  C4_TRY(dev_get(pool, (void **)&d_cnt, 4 * sizeof(uint32_t)));
   const Pend root = {0u, 0u};
   const uint32_t init[4] = {1u, 0u, 0u, 0u};  // node 0 = the root's four-wide node
   C4_TRY(hipMemcpy(d_pend, &root, sizeof(root), hipMemcpyHostToDevice));
@@ -210,18 +211,18 @@ int collapse_nodes4_device(const void *d_nodes, uint64_t n_nodes, Nodes4Device *
     err = fail;
   }
   if (rc) {
-    (void)hipFree(d_pend); (void)hipFree(d_tmp4); (void)hipFree(d_tmps); (void)hipFree(d_cnt);
+    dev_put(pool, d_pend); dev_put(pool, d_tmp4); dev_put(pool, d_tmps); dev_put(pool, d_cnt);
     return rc;
   }
   // exact-size copies (the bound above is about twice what a tree needs)
   const size_t nb = (total * sizeof(rtgpu_node4) + 63) / 64 * 64, sb = (total * 16 + 63) / 64 * 64;
-  C4_TRY(hipMalloc(&out->d_nodes4, nb));
-  C4_TRY(hipMalloc(&out->d_src, sb));
+  C4_TRY(dev_get(pool, &out->d_nodes4, nb));
+  C4_TRY(dev_get(pool, &out->d_src, sb));
   C4_TRY(hipMemset(out->d_nodes4, 0, nb));
   C4_TRY(hipMemset(out->d_src, 0, sb));
   C4_TRY(hipMemcpy(out->d_nodes4, d_tmp4, total * sizeof(rtgpu_node4), hipMemcpyDeviceToDevice));
   C4_TRY(hipMemcpy(out->d_src, d_tmps, total * 16, hipMemcpyDeviceToDevice));
-  (void)hipFree(d_pend); (void)hipFree(d_tmp4); (void)hipFree(d_tmps); (void)hipFree(d_cnt);
+  dev_put(pool, d_pend); dev_put(pool, d_tmp4); dev_put(pool, d_tmps); dev_put(pool, d_cnt);
   out->n_nodes4 = total;
   out->max_stack4 = cnt[1];
   out->gpu_ms = ms;

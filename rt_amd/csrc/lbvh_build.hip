@@ -32,6 +32,7 @@
 #include <string>
 #include <vector>
 
+#include "dev_pool.h"
 #include "rtgpu_internal.h"
 
 namespace {
@@ -300,12 +301,13 @@ __global__ void total_of_scan(const uint32_t *rank, const uint32_t *flag, int n,
   if (threadIdx.x == 0 && blockIdx.x == 0) *out = rank[n - 1] + flag[n - 1];
 }
 
-struct DevBufs {  // everything the build allocates besides its outputs; freed on every exit
+struct DevBufs {  // everything the build allocates besides its outputs; given back on every exit
+  rtgpu::DevPool *pool = nullptr;
   std::vector<void *> ptrs;
-  ~DevBufs() { for (void *p : ptrs) (void)hipFree(p); }
+  ~DevBufs() { for (void *p : ptrs) rtgpu::dev_put(pool, p); }
   template <typename T>
   hipError_t alloc(T **p, size_t n) {
-    hipError_t e = hipMalloc((void **)p, (n ? n : 1) * sizeof(T));
+    hipError_t e = rtgpu::dev_get(pool, (void **)p, (n ? n : 1) * sizeof(T));
     if (e == hipSuccess) ptrs.push_back(*p);
     return e;
   }
@@ -325,28 +327,29 @@ namespace rtgpu {
     hipError_t e_ = (call);                                                           \
     if (e_ != hipSuccess) {                                                           \
       err = std::string("lbvh: " #call ": ") + hipGetErrorString(e_);                 \
-      free_lbvh(out);                                                                 \
+      free_lbvh(out, pool);                                                                 \
       return 2;                                                                       \
     }                                                                                 \
   } while (0)
 
-void free_lbvh(LbvhDevice *out) {
+void free_lbvh(LbvhDevice *out, DevPool *pool) {
   if (!out) return;
-  (void)hipFree(out->d_nodes); (void)hipFree(out->d_tris); (void)hipFree(out->d_sphs); (void)hipFree(out->d_sph_meta);
+  dev_put(pool, out->d_nodes); dev_put(pool, out->d_tris); dev_put(pool, out->d_sphs); dev_put(pool, out->d_sph_meta);
   std::memset(out, 0, sizeof(*out));
 }
 
 // The current device must be the context's.  The scene must have passed
 // validate_scene.  Output arrays carry the zeroed tail records flatten_scene adds.
 int lbvh_build_device(const rtgpu_scene_desc *scene, LbvhDevice *out, std::string &err) {
-  return lbvh_build_device_ptrs(scene, nullptr, nullptr, out, err);
+  return lbvh_build_device_ptrs(scene, nullptr, nullptr, nullptr, out, err);
 }
 
 // The same with the primitive arrays already in device memory when d_spheres_in /
 // d_triangles_in are given (scene->spheres / ->triangles are then not read; the counts
 // are).  The arrays must have passed check_prims_device.
+// `pool`: where outputs and temporaries come from and go back to (NULL: hipMalloc / hipFree).
 int lbvh_build_device_ptrs(const rtgpu_scene_desc *scene, const void *d_spheres_in, const void *d_triangles_in,
-                           LbvhDevice *out, std::string &err) {
+                           DevPool *pool, LbvhDevice *out, std::string &err) {
   std::memset(out, 0, sizeof(*out));
   const bool on_device = d_spheres_in || d_triangles_in;
   const uint64_t ns64 = scene->n_spheres, nt64 = scene->n_triangles, P64 = ns64 + nt64;
@@ -359,10 +362,11 @@ int lbvh_build_device_ptrs(const rtgpu_scene_desc *scene, const void *d_spheres_
   }
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   DevBufs tmp;
-  LB_TRY(hipMalloc(&out->d_nodes, (size_t)n_inner * sizeof(rtgpu_node)));
-  LB_TRY(hipMalloc(&out->d_tris, ((size_t)nt + 8) * sizeof(rtgpu_tri)));
-  LB_TRY(hipMalloc(&out->d_sphs, ((size_t)ns + 8) * sizeof(rtgpu_sph)));
-  LB_TRY(hipMalloc(&out->d_sph_meta, ((size_t)ns * 2 + 16) * sizeof(uint32_t)));
+  tmp.pool = pool;
+  LB_TRY(dev_get(pool, &out->d_nodes, (size_t)n_inner * sizeof(rtgpu_node)));
+  LB_TRY(dev_get(pool, &out->d_tris, ((size_t)nt + 8) * sizeof(rtgpu_tri)));
+  LB_TRY(dev_get(pool, &out->d_sphs, ((size_t)ns + 8) * sizeof(rtgpu_sph)));
+  LB_TRY(dev_get(pool, &out->d_sph_meta, ((size_t)ns * 2 + 16) * sizeof(uint32_t)));
   LB_TRY(hipMemset(out->d_tris, 0, ((size_t)nt + 8) * sizeof(rtgpu_tri)));
   LB_TRY(hipMemset(out->d_sphs, 0, ((size_t)ns + 8) * sizeof(rtgpu_sph)));
   LB_TRY(hipMemset(out->d_sph_meta, 0, ((size_t)ns * 2 + 16) * sizeof(uint32_t)));
@@ -482,7 +486,7 @@ int lbvh_build_device_ptrs(const rtgpu_scene_desc *scene, const void *d_spheres_
     uint32_t left = (uint32_t)n_inner, pass = 0;
     const unsigned fit_blocks = std::min<unsigned>((unsigned)(((size_t)n_inner + kFitThreads - 1) / kFitThreads), 2048u);
     while (left != 0u) {
-      if (pass >= 64u) { err = "internal: lbvh fit did not finish in 64 level passes"; free_lbvh(out); return 3; }
+      if (pass >= 64u) { err = "internal: lbvh fit did not finish in 64 level passes"; free_lbvh(out, pool); return 3; }
       for (int k = 0; k < 8; k++) {
         pass++;
         const uint32_t *lin = (pass & 1u) ? d_list_b : d_list_a;   // pass 1 reads no list
@@ -515,7 +519,7 @@ int lbvh_build_device_ptrs(const rtgpu_scene_desc *scene, const void *d_spheres_
   out->max_depth = h0;
   (void)hipEventDestroy(ev0);
   (void)hipEventDestroy(ev1);
-  if (h0 > RTGPU_MAX_TREE_DEPTH) { err = "internal: LBVH deeper than RTGPU_MAX_TREE_DEPTH"; free_lbvh(out); return 3; }
+  if (h0 > RTGPU_MAX_TREE_DEPTH) { err = "internal: LBVH deeper than RTGPU_MAX_TREE_DEPTH"; free_lbvh(out, pool); return 3; }
   return 0;
 }
 

@@ -9,6 +9,8 @@
 
 namespace rtgpu {
 
+struct DevPool;  // dev_pool.h (device code only)
+
 // bvh_build.cpp
 int  flatten_scene(const rtgpu_scene_desc *scene, rtgpu_flat_scene *out, std::string &err);
 void free_flat_scene(rtgpu_flat_scene *fs);
@@ -28,8 +30,8 @@ struct Nodes4Device {
   uint32_t max_stack4 = 0;
   double gpu_ms = 0.0;
 };
-int  collapse_nodes4_device(const void *d_nodes, uint64_t n_nodes, Nodes4Device *out, std::string &err);
-void free_nodes4_device(Nodes4Device *out);
+int  collapse_nodes4_device(const void *d_nodes, uint64_t n_nodes, DevPool *pool, Nodes4Device *out, std::string &err);
+void free_nodes4_device(Nodes4Device *out, DevPool *pool);
 // pack48.hip: four-wide nodes re-read from refitted 64-byte nodes through their source map, on the device
 int  refresh_nodes4_device(const void *d_nodes, void *d_nodes4, const void *d_src, uint64_t n4, uint32_t *d_flag,
                            std::string &err);
@@ -45,9 +47,10 @@ struct LbvhDevice {
 };
 int  lbvh_build_device(const rtgpu_scene_desc *scene, LbvhDevice *out, std::string &err);
 // the same over rtgpu_sphere / rtgpu_triangle arrays in device memory (scene gives the counts only)
+// (pool: where outputs and temporaries come from and go back to; NULL = hipMalloc / hipFree)
 int  lbvh_build_device_ptrs(const rtgpu_scene_desc *scene, const void *d_spheres, const void *d_triangles,
-                            LbvhDevice *out, std::string &err);
-void free_lbvh(LbvhDevice *out);
+                            DevPool *pool, LbvhDevice *out, std::string &err);
+void free_lbvh(LbvhDevice *out, DevPool *pool);
 
 // refit.hip: new geometry under the uploaded tree's topology, in place on the device arrays
 // (ws: device scratch of refit_workspace_words(n_nodes) u32 kept between refits, or NULL)

@@ -28,6 +28,7 @@
 #include <string>
 #include <vector>
 
+#include "dev_pool.h"
 #include "rtgpu_internal.h"
 
 namespace {
@@ -1027,6 +1028,7 @@ struct rtgpu_ctx {
   void *d_nodes4 = nullptr;     // four-wide packed nodes of such a tree, else NULL
   void *d_nodes4_src = nullptr; // their source map (4 u32 per node), read by a refit
   uint32_t *d_refit_ws = nullptr; // refit scratch (3 u32 per node), allocated by the first refit of a scene
+  rtgpu::DevPool pool;            // device memory kept between rtgpu_build_device calls (dev_pool.h)
   bool no_wide = false;         // RTGPU_NO_WIDE=1: keep the BVH2 traversal on large trees (experiments)
   unsigned long long *d_counters = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -1083,9 +1085,10 @@ bool hip_fail(rtgpu_ctx *ctx, hipError_t e, const char *what) {
   } while (0)
 
 void free_scene_device(rtgpu_ctx *ctx) {
-  (void)hipFree(ctx->d_nodes);  (void)hipFree(ctx->d_tris);  (void)hipFree(ctx->d_sphs);
-  (void)hipFree(ctx->d_sph_meta);  (void)hipFree(ctx->d_mats);  (void)hipFree(ctx->d_nodes48);
-  (void)hipFree(ctx->d_nodes4);  (void)hipFree(ctx->d_nodes4_src);  (void)hipFree(ctx->d_refit_ws);
+  // arrays that came from the context's pool go back to it, the others are hipFree'd
+  for (void *p : {ctx->d_nodes, ctx->d_tris, ctx->d_sphs, ctx->d_sph_meta, ctx->d_mats, ctx->d_nodes48, ctx->d_nodes4,
+                  ctx->d_nodes4_src, (void *)ctx->d_refit_ws})
+    ctx->pool.put(p);
   ctx->d_refit_ws = nullptr;
   ctx->d_nodes = ctx->d_tris = ctx->d_sphs = ctx->d_sph_meta = ctx->d_mats = ctx->d_nodes48 = ctx->d_nodes4 = nullptr;
   ctx->d_nodes4_src = nullptr;
@@ -1210,6 +1213,7 @@ extern "C" void rtgpu_destroy(rtgpu_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipDeviceSynchronize();  // a frame begun and never ended may still be running
   free_scene_device(ctx);
+  ctx->pool.trim();
   (void)hipFree(ctx->d_counters);
   (void)hipFree(ctx->d_ovf);
   (void)hipFree(ctx->d_wave_times);
@@ -1229,6 +1233,7 @@ extern "C" int rtgpu_upload_scene(rtgpu_ctx *ctx, const rtgpu_scene_desc *scene)
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipDeviceSynchronize());
   free_scene_device(ctx);
+  ctx->pool.trim();
   if (rtgpu::flatten_scene(scene, &ctx->host, ctx->err)) return 1;
   if (ctx->no_wide && ctx->host.nodes4) {  // RTGPU_NO_WIDE: the oracle must see what the kernel traverses
     std::free((void *)ctx->host.nodes4);
@@ -1258,7 +1263,8 @@ extern "C" int rtgpu_upload_scene(rtgpu_ctx *ctx, const rtgpu_scene_desc *scene)
 }
 
 namespace {
-int upload_lbvh_common(rtgpu_ctx *ctx, const rtgpu_scene_desc *scene, const void *d_spheres, const void *d_triangles);
+int upload_lbvh_common(rtgpu_ctx *ctx, const rtgpu_scene_desc *scene, const void *d_spheres, const void *d_triangles,
+                       bool from_device);
 }
 
 // As rtgpu_upload_scene, with the BVH built on the GPU (lbvh_build.hip).
@@ -1268,8 +1274,9 @@ extern "C" int rtgpu_upload_scene_lbvh(rtgpu_ctx *ctx, const rtgpu_scene_desc *s
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipDeviceSynchronize());
   free_scene_device(ctx);
+  ctx->pool.trim();
   if (rtgpu::validate_scene(scene, ctx->err)) return 1;
-  return upload_lbvh_common(ctx, scene, nullptr, nullptr);
+  return upload_lbvh_common(ctx, scene, nullptr, nullptr, false);
 }
 
 // The same for primitives that already live in GPU memory (a simulation or a loader wrote
@@ -1295,15 +1302,20 @@ extern "C" int rtgpu_build_device(rtgpu_ctx *ctx, const void *d_spheres, uint64_
     return rc;
   scene.n_spheres = n_spheres;
   scene.n_triangles = n_triangles;
-  return upload_lbvh_common(ctx, &scene, n_spheres ? d_spheres : nullptr, n_triangles ? d_triangles : nullptr);
+  // outputs and temporaries come from the context's pool: a frame loop that builds every
+  // frame asks for the same sizes each time (dev_pool.h)
+  int rc = upload_lbvh_common(ctx, &scene, n_spheres ? d_spheres : nullptr, n_triangles ? d_triangles : nullptr, true);
+  ctx->pool.end_of_build();
+  return rc;
 }
 
 namespace {
 // scene: validated; its primitive arrays are read from d_spheres / d_triangles when given
-int upload_lbvh_common(rtgpu_ctx *ctx, const rtgpu_scene_desc *scene, const void *d_spheres, const void *d_triangles) {
+int upload_lbvh_common(rtgpu_ctx *ctx, const rtgpu_scene_desc *scene, const void *d_spheres, const void *d_triangles,
+                       bool from_device) {
   rtgpu::LbvhDevice L;
-  int rc = (d_spheres || d_triangles) ? rtgpu::lbvh_build_device_ptrs(scene, d_spheres, d_triangles, &L, ctx->err)
-                                      : rtgpu::lbvh_build_device(scene, &L, ctx->err);
+  rtgpu::DevPool *pool = from_device ? &ctx->pool : nullptr;  // rtgpu_build_device works from the pool
+  int rc = rtgpu::lbvh_build_device_ptrs(scene, d_spheres, d_triangles, pool, &L, ctx->err);
   if (rc) return rc;
   ctx->d_nodes = L.d_nodes; ctx->d_tris = L.d_tris; ctx->d_sphs = L.d_sphs; ctx->d_sph_meta = L.d_sph_meta;
   // The host copy of the flattened scene (what rtgpu_get_flat_scene hands out) is made on
@@ -1327,7 +1339,7 @@ int upload_lbvh_common(rtgpu_ctx *ctx, const rtgpu_scene_desc *scene, const void
   }
   if (h.n_nodes >= RTGPU_NODE48_MIN_NODES) {
     const size_t pb = (size_t)h.n_nodes * sizeof(rtgpu_node48);
-    hipError_t e = hipMalloc(&ctx->d_nodes48, (pb + 63) / 64 * 64);
+    hipError_t e = rtgpu::dev_get(pool, &ctx->d_nodes48, (pb + 63) / 64 * 64);
     if (e != hipSuccess) {
       ctx->err = std::string("lbvh: packed nodes: ") + hipGetErrorString(e);
       free_scene_device(ctx);
@@ -1341,7 +1353,7 @@ int upload_lbvh_common(rtgpu_ctx *ctx, const rtgpu_scene_desc *scene, const void
     }
     if (!ctx->no_wide) {  // four-wide nodes: collapsed on the device (collapse4.hip)
       rtgpu::Nodes4Device w;
-      if (int crc = rtgpu::collapse_nodes4_device(ctx->d_nodes, h.n_nodes, &w, perr)) {
+      if (int crc = rtgpu::collapse_nodes4_device(ctx->d_nodes, h.n_nodes, pool, &w, perr)) {
         free_scene_device(ctx);
         ctx->err = perr;
         return crc;
