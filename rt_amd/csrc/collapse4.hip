@@ -178,9 +178,10 @@ int collapse_nodes4_device(const void *d_nodes, uint64_t n_nodes, DevPool *pool,
   C4_TRY(hipMemcpy(d_pend, &root, sizeof(root), hipMemcpyHostToDevice));
   C4_TRY(hipMemcpy(d_cnt, init, sizeof(init), hipMemcpyHostToDevice));
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  if (hipEventCreate(&ev0) != hipSuccess || hipEventCreate(&ev1) != hipSuccess) {
-    if (ev0) (void)hipEventDestroy(ev0);
-    C4_TRY(hipErrorOutOfMemory);
+  {
+    hipError_t e = hipEventCreate(&ev0);
+    if (e == hipSuccess && (e = hipEventCreate(&ev1)) != hipSuccess) (void)hipEventDestroy(ev0);
+    C4_TRY(e);
   }
   (void)hipEventRecord(ev0, 0);
   uint32_t first = 0, end = 1, cnt[4] = {1u, 0u, 0u, 0u};
