@@ -323,6 +323,9 @@ int  rtgpu_scene_load_obj(const char *path, rtgpu_scene_desc *out);
 /* Resolved frame (0xRRGGBBAA, row 0 = bottom, as rtgpu_resolve_rgba8 writes it)
  * -> binary PPM (P6), rows flipped to top-down, alpha dropped. */
 int  rtgpu_write_ppm(const char *path, const uint32_t *rgba8, uint32_t width, uint32_t height);
+/* The same image as an 8-bit RGBA PNG (rows top-down, alpha kept; stored deflate
+ * blocks, so no compression library is involved). */
+int  rtgpu_write_png(const char *path, const uint32_t *rgba8, uint32_t width, uint32_t height);
 
 #ifdef __cplusplus
 }

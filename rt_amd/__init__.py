@@ -18,6 +18,7 @@ from .api import (  # noqa: F401
     default_settings,
     lib,
     look_at,
+    write_png,
     write_ppm,
     MATERIAL_DTYPE,
     SPHERE_DTYPE,

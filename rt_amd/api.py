@@ -168,6 +168,7 @@ lib.rtgpu_scene_free.restype = None
 lib.rtgpu_scene_parse_obj.argtypes = [C.c_char_p, C.c_uint64, _P(SceneDesc)]
 lib.rtgpu_scene_load_obj.argtypes = [C.c_char_p, _P(SceneDesc)]
 lib.rtgpu_write_ppm.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32]
+lib.rtgpu_write_png.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32]
 
 
 def _global_error():
@@ -197,6 +198,14 @@ def write_ppm(path, rgba8):
     a = np.ascontiguousarray(rgba8, np.uint32)
     h, w = a.shape
     if lib.rtgpu_write_ppm(str(path).encode(), a.ctypes.data, w, h):
+        raise RtgpuError(_global_error())
+
+
+def write_png(path, rgba8):
+    """The same image as an 8-bit RGBA PNG (rtgpu_write_png)."""
+    a = np.ascontiguousarray(rgba8, np.uint32)
+    h, w = a.shape
+    if lib.rtgpu_write_png(str(path).encode(), a.ctypes.data, w, h):
         raise RtgpuError(_global_error())
 
 

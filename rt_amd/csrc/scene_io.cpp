@@ -9,6 +9,7 @@
 // (code/gfx/gfx.hpp:4-6), image rows bottom-up (code/math/mat.cxx:104-129).
 #include "rtgpu_internal.h"
 
+#include <algorithm>
 #include <cerrno>
 #include <cmath>
 #include <cstdio>
@@ -180,3 +181,84 @@ extern "C" int rtgpu_write_ppm(const char *path, const uint32_t *rgba8, uint32_t
   if (std::fclose(f) != 0) return fail(std::string("ppm: write error on ") + path);
   return 0;
 }
+
+// PNG (8-bit RGBA, no interlace) with the image data in stored deflate blocks: no
+// compression library is needed and every viewer reads it.  Rows flipped to top-down as
+// in the PPM; the alpha byte is kept.
+namespace {
+struct Crc32 {
+  uint32_t table[256];
+  Crc32() {
+    for (uint32_t n = 0; n < 256; n++) {
+      uint32_t c = n;
+      for (int k = 0; k < 8; k++) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+      table[n] = c;
+    }
+  }
+  uint32_t update(uint32_t crc, const unsigned char *p, size_t n) const {
+    for (size_t i = 0; i < n; i++) crc = table[(crc ^ p[i]) & 0xFFu] ^ (crc >> 8);
+    return crc;
+  }
+};
+void put_be32(unsigned char *p, uint32_t v) { p[0] = (unsigned char)(v >> 24); p[1] = (unsigned char)(v >> 16); p[2] = (unsigned char)(v >> 8); p[3] = (unsigned char)v; }
+bool write_chunk(std::FILE *f, const Crc32 &crc, const char type[4], const unsigned char *data, size_t n) {
+  unsigned char head[8], tail[4];
+  put_be32(head, (uint32_t)n);
+  std::memcpy(head + 4, type, 4);
+  uint32_t c = crc.update(0xFFFFFFFFu, head + 4, 4);
+  c = crc.update(c, data, n);
+  put_be32(tail, c ^ 0xFFFFFFFFu);
+  return std::fwrite(head, 1, 8, f) == 8 && (n == 0 || std::fwrite(data, 1, n, f) == n) && std::fwrite(tail, 1, 4, f) == 4;
+}
+}  // namespace
+
+extern "C" int rtgpu_write_png(const char *path, const uint32_t *rgba8, uint32_t width, uint32_t height) {
+  if (!path || !rgba8 || width == 0 || height == 0) return fail("png: bad arguments");
+  const size_t row_bytes = (size_t)width * 4 + 1;  // filter byte + pixels
+  const size_t raw = row_bytes * height;
+  if (raw >= (1ull << 31)) return fail("png: image too large for one IDAT chunk");
+  // zlib stream: header, stored blocks of at most 65535 bytes, Adler-32 of the raw data
+  const size_t n_blocks = (raw + 65534) / 65535;
+  std::vector<unsigned char> z;
+  z.reserve(2 + raw + 5 * n_blocks + 4);
+  z.push_back(0x78);
+  z.push_back(0x01);
+  std::vector<unsigned char> data(raw);
+  for (uint32_t y = 0; y < height; y++) {
+    const uint32_t *src = rgba8 + (size_t)(height - 1 - y) * width;
+    unsigned char *dst = &data[y * row_bytes];
+    dst[0] = 0;  // filter: none
+    for (uint32_t x = 0; x < width; x++) put_be32(dst + 1 + 4 * (size_t)x, src[x]);  // 0xRRGGBBAA -> R G B A
+  }
+  uint32_t a = 1, b = 0;
+  for (size_t i = 0; i < raw;) {  // Adler-32, sums reduced every 5552 bytes
+    const size_t n = std::min<size_t>(5552, raw - i);
+    for (size_t k = 0; k < n; k++) { a += data[i + k]; b += a; }
+    a %= 65521u; b %= 65521u;
+    i += n;
+  }
+  for (size_t i = 0; i < raw; i += 65535) {
+    const size_t n = std::min<size_t>(65535, raw - i);
+    z.push_back(i + n == raw ? 1 : 0);  // BFINAL, BTYPE = 00
+    z.push_back((unsigned char)(n & 0xFF)); z.push_back((unsigned char)(n >> 8));
+    z.push_back((unsigned char)(~n & 0xFF)); z.push_back((unsigned char)((~n >> 8) & 0xFF));
+    z.insert(z.end(), data.begin() + (std::ptrdiff_t)i, data.begin() + (std::ptrdiff_t)(i + n));
+  }
+  unsigned char ad[4];
+  put_be32(ad, (b << 16) | a);
+  z.insert(z.end(), ad, ad + 4);
+  std::FILE *f = std::fopen(path, "wb");
+  if (!f) return fail(std::string("png: cannot open ") + path + ": " + std::strerror(errno));
+  static const Crc32 crc;
+  static const unsigned char sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+  unsigned char ihdr[13];
+  put_be32(ihdr, width);
+  put_be32(ihdr + 4, height);
+  ihdr[8] = 8; ihdr[9] = 6; ihdr[10] = 0; ihdr[11] = 0; ihdr[12] = 0;  // 8 bit, RGBA, deflate, adaptive, no interlace
+  bool ok = std::fwrite(sig, 1, 8, f) == 8 && write_chunk(f, crc, "IHDR", ihdr, 13) &&
+            write_chunk(f, crc, "IDAT", z.data(), z.size()) && write_chunk(f, crc, "IEND", nullptr, 0);
+  if (std::fclose(f) != 0) ok = false;
+  if (!ok) return fail(std::string("png: write error on ") + path);
+  return 0;
+}
+

@@ -115,6 +115,10 @@ void rt_write_ppm_or_panic(char const *path, u32 const *rgba8, u32 width, u32 he
   if (::rtgpu_write_ppm(path, rgba8, width, height) != 0) errf("rt: %s", ::rtgpu_last_error(nullptr));
 }
 
+void rt_write_png_or_panic(char const *path, u32 const *rgba8, u32 width, u32 height) {
+  if (::rtgpu_write_png(path, rgba8, width, height) != 0) errf("rt: %s", ::rtgpu_last_error(nullptr));
+}
+
 f32 rt_last_kernel_ms() {
   f32 ms = 0.f;
   if (::rtgpu_last_kernel_ms(gRt_Ctx, &ms) != 0) return -1.f;

@@ -122,4 +122,5 @@ void rt_resolve_rgba8_or_panic(Vec4 const *accum, u32 *rgba8_out, s64 pixel_coun
 void rt_scene_free(Scene &scene);
 // rgba8: 0xRRGGBBAA, row 0 = bottom (what rt_resolve_rgba8_or_panic writes)
 void rt_write_ppm_or_panic(char const *path, u32 const *rgba8, u32 width, u32 height);
+void rt_write_png_or_panic(char const *path, u32 const *rgba8, u32 width, u32 height);
 }  // namespace rt

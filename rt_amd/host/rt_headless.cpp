@@ -100,7 +100,10 @@ int main(int argc, char **argv) {
               (unsigned long long)stats.rays, rt_last_kernel_ms(),
               (double)stats.rays / (rt_last_kernel_ms() * 1e3), ms, (long long)pumped);
 
-  rt_write_ppm_or_panic(out_path, rgba, width, height);  // where Present would be
+  // where Present would be: PNG if the name says so, else PPM
+  size_t const path_len = strlen(out_path);
+  if (path_len > 4 && strcmp(out_path + path_len - 4, ".png") == 0) rt_write_png_or_panic(out_path, rgba, width, height);
+  else rt_write_ppm_or_panic(out_path, rgba, width, height);
   std::printf("wrote %s\n", out_path);
   rt_scene_free(scene);
   rt_shutdown();
