@@ -206,3 +206,29 @@ def test_build_from_device_arrays(ra, oracle, gpu_ctx):
         gpu_ctx.build_device(None, 3, None, 0, scene.materials)
     with pytest.raises(ra.RtgpuError, match="no scene"):
         gpu_ctx.render(cam, st)
+
+
+@pytest.mark.gpu
+def test_repeated_device_builds_do_not_grow_gpu_memory(ra, gpu_ctx):
+    """The context's pool (dev_pool.h): a frame loop of rtgpu_build_device calls reaches a
+    steady state, blocks of sizes no longer asked for are freed after two builds, and an
+    upload from host arrays releases what the pool kept."""
+    import torch
+    scene, _ = ra.Scene.builtin(1, param=7)                       # 328 k triangles
+    d_tri = torch.from_numpy(scene.triangles.view(np.uint8).copy()).cuda()
+    n = len(scene.triangles)
+    small, _ = ra.Scene.builtin(0)
+    gpu_ctx.upload(small)
+    torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info()[0]
+    used = []
+    for k in range(8):
+        gpu_ctx.build_device(None, 0, d_tri.data_ptr(), n, scene.materials)
+        used.append(free_before - torch.cuda.mem_get_info()[0])
+    assert used[0] > 50 * n                                       # the scene itself is tens of bytes per triangle
+    assert max(used[2:]) == min(used[2:]), used                   # steady state from the third build on
+    for k in range(3):                                            # a much smaller scene: the big blocks must go
+        gpu_ctx.build_device(None, 0, d_tri.data_ptr(), n // 16, scene.materials)
+    assert free_before - torch.cuda.mem_get_info()[0] < used[-1] // 4
+    gpu_ctx.upload(small)                                         # host path: pool released
+    assert abs(free_before - torch.cuda.mem_get_info()[0]) < (8 << 20)
