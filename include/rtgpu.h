@@ -182,7 +182,7 @@ int  rtgpu_upload_scene(rtgpu_ctx *ctx, const rtgpu_scene_desc *scene);
 /* SURVEY.md §8f row 3 (no reference counterpart): as rtgpu_upload_scene, but the
  * BVH is built on the GPU - Morton codes, one radix sort, Karras' parallel
  * hierarchy (HPG 2012), level-by-level box fit - straight into the same
- * flattened format, one primitive per leaf.  Builds in milliseconds where the
+ * flattened format, one primitive (or two triangles) per leaf.  Builds in milliseconds where the
  * host SAH build takes seconds, for a tree that costs more node visits per ray;
  * meant for scenes that change.  The packed copy and the four-wide nodes of the tree
  * are made on the GPU too; rtgpu_get_flat_scene copies the result back when it is

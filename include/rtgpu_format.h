@@ -44,6 +44,14 @@ typedef struct rtgpu_node {
 typedef struct rtgpu_node48 {
   uint32_t w[12];
 } rtgpu_node48;
+/* GPU LBVH builder (rt_amd/csrc/lbvh_build.hip, restated in oracle/rt_oracle.c): a subtree
+ * of at most this many TRIANGLES (and nothing else) becomes a single leaf; its triangles
+ * are adjacent in the leaf-ordered array.  The trace loop tests two triangles per leaf
+ * step, so a leaf of two costs what a leaf of one does and saves a node.  Spheres stay
+ * one per leaf. */
+#ifndef RTGPU_LBVH_MAX_LEAF
+#define RTGPU_LBVH_MAX_LEAF 2u
+#endif
 #define RTGPU_NODE48_MIN_NODES 1366u
 
 /* Four-wide packed node, 96 bytes, 16-byte aligned: up to four children per node,

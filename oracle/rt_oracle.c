@@ -1110,6 +1110,7 @@ RTO_API int rto_build_lbvh(const rtgpu_scene_desc *sc, rtgpu_flat_scene *out) {
   }
 
   uint32_t max_depth = 0;
+  int64_t n_emitted = n_inner;  /* nodes merged into leaves are not emitted */
   if (P <= 1) {
     for (int k = 0; k < 3; k++) {
       nodes[0].lo0[k] = nodes[0].lo1[k] = INFINITY;
@@ -1147,6 +1148,11 @@ RTO_API int rto_build_lbvh(const rtgpu_scene_desc *sc, rtgpu_flat_scene *out) {
     /* boxes, sizes, heights bottom-up (a child always has ... no index order: iterate until done) */
     box_t *nbox = malloc(sizeof(box_t) * (size_t)n_inner);
     uint32_t *size = calloc((size_t)n_inner, sizeof(uint32_t)), *height = calloc((size_t)n_inner, sizeof(uint32_t));
+    /* kind: 1 = only spheres below the node, 2 = only triangles, 0 = both; lo_pos: lowest sorted
+     * position below it.  Triangles only and size <= RTGPU_LBVH_MAX_LEAF: the node is MERGED into one
+     * leaf of its parent (lbvh_build.hip fit_pass / emit_nodes). */
+    uint32_t *kind = calloc((size_t)n_inner, sizeof(uint32_t)), *lo_pos = calloc((size_t)n_inner, sizeof(uint32_t));
+#define LBVH_MERGED(i) (kind[i] == 2u && size[i] <= RTGPU_LBVH_MAX_LEAF)
     uint8_t *done = calloc((size_t)n_inner, 1);
     /* explicit stack post-order from the root */
     int64_t *stk = malloc(sizeof(int64_t) * 256);
@@ -1171,21 +1177,47 @@ RTO_API int rto_build_lbvh(const rtgpu_scene_desc *sc, rtgpu_flat_scene *out) {
       }
       uint32_t sa = a < 0 ? 1 : size[a], sb = b < 0 ? 1 : size[b];
       uint32_t ha = a < 0 ? 0 : height[a], hb = b < 0 ? 0 : height[b];
+      uint32_t ka = a < 0 ? ((uint32_t)keys[~a] < (uint32_t)ns ? 1u : 2u) : kind[a];
+      uint32_t kb = b < 0 ? ((uint32_t)keys[~b] < (uint32_t)ns ? 1u : 2u) : kind[b];
       size[i] = sa + sb;
-      height[i] = 1 + (ha > hb ? ha : hb);
+      kind[i] = ka == kb ? ka : 0u;
+      lo_pos[i] = a < 0 ? (uint32_t)~a : lo_pos[a];
+      /* the root stays a node even when everything below it merges */
+      height[i] = LBVH_MERGED(i) ? (i == 0 ? 1u : 0u) : 1 + (ha > hb ? ha : hb);
       done[i] = 1;
     }
     max_depth = height[0];
     /* renumber: top nodes (subtree >= T prims) first, both groups in Karras order */
     uint32_t T = (uint32_t)((2 * P + 4095) / 4096);
     if (T < 1) T = 1;
+    /* emitted: the root and every node that is not merged (a merged node's ancestors up to the
+     * first unmerged one are merged too, so "not merged" = "not inside a leaf") */
     uint32_t *new_of = malloc(sizeof(uint32_t) * (size_t)n_inner);
-    uint32_t n_top = 0;
-    for (int64_t i = 0; i < n_inner; i++) n_top += size[i] >= T;
-    uint32_t at_top = 0, at_rest = n_top;
-    for (int64_t i = 0; i < n_inner; i++) new_of[i] = size[i] >= T ? at_top++ : at_rest++;
+    uint32_t n_top = 0, n_rest = 0;
+#define LBVH_KEEP(i) ((i) == 0 || !LBVH_MERGED(i))
     for (int64_t i = 0; i < n_inner; i++) {
+      if (!LBVH_KEEP(i)) continue;
+      if (size[i] >= T) n_top++; else n_rest++;
+    }
+    uint32_t at_top = 0, at_rest = n_top;
+    for (int64_t i = 0; i < n_inner; i++) {
+      new_of[i] = 0xFFFFFFFFu;
+      if (LBVH_KEEP(i)) new_of[i] = size[i] >= T ? at_top++ : at_rest++;
+    }
+    n_emitted = (int64_t)n_top + n_rest;
+    for (int64_t i = 0; i < n_inner; i++) {
+      if (!LBVH_KEEP(i)) continue;
       rtgpu_node *nd = &nodes[new_of[i]];
+      nd->_pad[0] = nd->_pad[1] = 0;
+      if (LBVH_MERGED(i)) {  /* i == 0: one leaf and an EMPTY sibling */
+        for (int k = 0; k < 3; k++) {
+          nd->lo0[k] = nbox[i].lo[k]; nd->hi0[k] = nbox[i].hi[k];
+          nd->lo1[k] = INFINITY; nd->hi1[k] = INFINITY;
+        }
+        nd->child0 = leaf_ref[lo_pos[i]] | ((size[i] - 1u) << 27);
+        nd->child1 = RTGPU_REF_EMPTY;
+        continue;
+      }
       int64_t a = c0[i], b = c1[i];
       const box_t *ba = a < 0 ? &pbox[(uint32_t)keys[~a]] : &nbox[a];
       const box_t *bb = b < 0 ? &pbox[(uint32_t)keys[~b]] : &nbox[b];
@@ -1193,21 +1225,23 @@ RTO_API int rto_build_lbvh(const rtgpu_scene_desc *sc, rtgpu_flat_scene *out) {
         nd->lo0[k] = ba->lo[k]; nd->hi0[k] = ba->hi[k];
         nd->lo1[k] = bb->lo[k]; nd->hi1[k] = bb->hi[k];
       }
-      nd->child0 = a < 0 ? leaf_ref[~a] : new_of[a];
-      nd->child1 = b < 0 ? leaf_ref[~b] : new_of[b];
-      nd->_pad[0] = nd->_pad[1] = 0;
+      nd->child0 = a < 0 ? leaf_ref[~a] : LBVH_MERGED(a) ? (leaf_ref[lo_pos[a]] | ((size[a] - 1u) << 27)) : new_of[a];
+      nd->child1 = b < 0 ? leaf_ref[~b] : LBVH_MERGED(b) ? (leaf_ref[lo_pos[b]] | ((size[b] - 1u) << 27)) : new_of[b];
     }
+#undef LBVH_KEEP
+#undef LBVH_MERGED
+    free(kind); free(lo_pos);
     free(c0); free(c1); free(nbox); free(size); free(height); free(done); free(stk); free(new_of);
   }
   free(keys); free(pbox); free(leaf_ref);
-  out->nodes = nodes; out->n_nodes = (uint64_t)n_inner;
+  out->nodes = nodes; out->n_nodes = (uint64_t)n_emitted;
   out->tris = tris; out->n_tris = (uint64_t)nt;
   out->spheres = sphs; out->n_spheres = (uint64_t)ns;
   out->sphere_meta = meta;
   out->materials = mats; out->n_materials = sc->n_materials;
   out->max_depth = max_depth;
   int pfail;
-  out->nodes48 = pack_all(nodes, (uint64_t)n_inner, &pfail);
+  out->nodes48 = pack_all(nodes, (uint64_t)n_emitted, &pfail);
   if (pfail) return 4;
   return 0;
 }
