@@ -353,6 +353,9 @@ void trace_kernel(const KParams P) {
   // closest hit so far: the leaf cursor at the time of the hit (type bit + slot of the
   // primitive in its leaf-ordered array), kDone = none
   uint32_t hit_ref = kDone;
+  // material index of the closest TRIANGLE hit so far, taken from the record the test has in
+  // registers: shading then fetches the material together with the triangle instead of after it
+  uint32_t hit_mat = 0u;
   unsigned pool_next = 0, pool_end = 0;  // wave-local slice of the work queue (wave-uniform)
   // wave-uniform description of the group the pool was drawn from (see (2))
   uint32_t g_px = 0, g_py = 0, g_out = 0, g_row = 0, g_chunk = 0, g_sample = 0, g_sample_end = 0;
@@ -411,27 +414,28 @@ void trace_kernel(const KParams P) {
       } else {
         V3 p = ro + rd * tbest;
         V3 n;
-        uint32_t prim, mat;
+        uint32_t prim;
+        float4 m0, m1;
         if (hit_ref & RTGPU_REF_SPHERE) {
           float4 s = P.sphs[hit_slot];
           uint2 meta = P.sph_meta[hit_slot];
           float inv_r = rcp_exact(s.w);
           n = (p - mk(s.x, s.y, s.z)) * inv_r;
           prim = meta.x;
-          mat = meta.y;
+          m0 = P.mats[meta.y * 2u]; m1 = P.mats[meta.y * 2u + 1u];
         } else {
+          // the material index came with the hit: its two loads go out with the triangle's
           const float4 *tp = P.tris + (size_t)hit_slot * (sizeof(rtgpu_tri) / 16);
           float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
+          m0 = P.mats[hit_mat * 2u]; m1 = P.mats[hit_mat * 2u + 1u];
           n = normalize(cross(mk(t1.x, t1.y, t1.z), mk(t2.x, t2.y, t2.z)));
           prim = __float_as_uint(t0.w);
-          mat = __float_as_uint(t1.w);
         }
         if (bounce == 0 && sample == 0) first_id = prim;
         float dn = dot(rd, n);
         bool front = dn < 0.0f;
         if (!front) n = neg(n);
 
-        float4 m0 = P.mats[mat * 2u], m1 = P.mats[mat * 2u + 1u];
         V3 albedo = mk(m0.x, m0.y, m0.z);
         float param = m0.w;
         uint32_t mtype = __float_as_uint(m1.x);
@@ -866,7 +870,11 @@ void trace_kernel(const KParams P) {
                 valid = valid && !(v < 0.0f || u + v > 1.0f);
                 float t = dot(e2, qvec) * inv_det;
                 // the leaf cursor as it stands at this test: first + k, count - k
-                if (valid && t > tmin && t < tbest) { tbest = t; hit_ref = cur + (uint32_t)k - ((uint32_t)k << 27); }
+                if (valid && t > tmin && t < tbest) {
+                  tbest = t;
+                  hit_ref = cur + (uint32_t)k - ((uint32_t)k << 27);
+                  hit_mat = __float_as_uint(b.w);
+                }
               }
             }
           }
