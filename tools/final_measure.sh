@@ -1,7 +1,8 @@
 #!/bin/bash
 # Round-end measurement set for the current build, one GPU call:
 #   GPU parity tests -> bench.py -> rocprofv3 kernel stats of the same bench
-#   command -> FETCH_SIZE calibration -> C2 PMC passes.
+#   command -> FETCH_SIZE calibration -> C2 / C3 PMC passes -> perf survey ->
+#   phase profile -> full-size parity against the oracle.
 # usage (on the GPU box): bash tools/final_measure.sh <tag>
 set -e -o pipefail
 TAG=${1:-final}
@@ -24,3 +25,5 @@ timeout -k 10 200 python3 tools/gpu_perf.py c2 c3 c5 c5full > "$OUT/perf.log" 2>
 cat "$OUT/perf.log"
 timeout -k 10 200 python3 tools/gpu_divergence.py c2 c3 c5 > "$OUT/divergence.log" 2>&1
 cat "$OUT/divergence.log"
+timeout -k 10 600 python3 -u tools/gpu_full_parity.py 16 2>/dev/null | grep -v amdgpu.ids > "$OUT/full_parity.txt"
+tail -1 "$OUT/full_parity.txt"

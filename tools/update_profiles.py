@@ -10,7 +10,7 @@ os.makedirs(dest, exist_ok=True)
 shutil.copy(glob.glob(os.path.join(src, "stats", "**", "*_kernel_stats.csv"), recursive=True)[0], os.path.join(dest, "kernel_stats.csv"))
 for a, b in (("pmc_c2/summary.txt", "pmc_c2_summary.txt"), ("pmc_c3/summary.txt", "pmc_c3_summary.txt"),
              ("bench_under_rocprof.json", "bench_under_rocprof.json"), ("perf.log", "perf_survey.txt"),
-             ("divergence.log", "divergence.txt")):
+             ("divergence.log", "divergence.txt"), ("full_parity.txt", "full_size_parity.txt")):
     if os.path.exists(os.path.join(src, a)):
         shutil.copy(os.path.join(src, a), os.path.join(dest, b))
 pmc = {}
