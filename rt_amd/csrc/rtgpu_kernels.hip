@@ -17,9 +17,10 @@
 // item = (pixel, chunk of samples) at a time and walks its samples in order; work
 // items come from a global queue in groups of 64 (one atomic per group), chunk
 // sums go to per-chunk planes and combine_kernel adds them in order, which keeps
-// the frame sum deterministic.  Traversal runs in voted phases (node steps /
-// one-primitive leaf steps) and is left early when few lanes still traverse, so
-// finished lanes shade and start their next ray.
+// the frame sum deterministic.  Traversal runs in voted phases (node steps over
+// 64-byte, packed 48-byte or four-wide 96-byte nodes / leaf steps of one primitive,
+// or two triangles) and is left early when few lanes still traverse, so finished
+// lanes shade and start their next ray.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
