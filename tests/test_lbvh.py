@@ -236,3 +236,35 @@ def test_repeated_device_builds_do_not_grow_gpu_memory(ra, gpu_ctx):
     assert free_before - torch.cuda.mem_get_info()[0] < used[-1] // 4
     gpu_ctx.upload(small)                                         # host path: pool released
     assert abs(free_before - torch.cuda.mem_get_info()[0]) < (8 << 20)
+
+
+def test_oracle_lbvh_merges_triangle_pairs_and_nothing_else(ra, oracle):
+    """CPU only: the leaf rule of the builder (RTGPU_LBVH_MAX_LEAF = 2, triangles only).  No
+    sphere leaf holds more than one sphere, no triangle leaf more than two triangles, and no
+    emitted node is left with two single-triangle leaves (such a node is merged into one
+    leaf of its parent) - except the root, which always stays a node."""
+    for name, scene in _scenes(ra).items():
+        fs = oracle.build_lbvh(scene.desc, FlatSceneC)
+        try:
+            nodes = np.frombuffer(_flat_bytes(fs)["nodes"], np.uint32).reshape(-1, 16)
+            refs = nodes[:, 12:14]
+            leaf = (refs & 0x80000000) != 0
+            empty = refs == 0xFFFFFFFF
+            sphere = leaf & ~empty & ((refs & 0x40000000) != 0)
+            tri = leaf & ~empty & ((refs & 0x40000000) == 0)
+            count = ((refs >> 27) & 7) + 1
+            assert (count[sphere] == 1).all(), name
+            assert (count[tri] <= 2).all(), name
+            single_tri = tri & (count == 1)
+            both_single = single_tri[:, 0] & single_tri[:, 1]
+            assert not both_single[1:].any(), name
+            if len(scene.triangles) >= 2 and len(scene.spheres) == 0:
+                assert (count[tri] == 2).any(), name                 # something did merge
+            # every triangle is referenced exactly once, pairs included
+            first = refs & 0x07FFFFFF
+            seen = np.zeros(fs.n_tris + 1, np.int64)
+            for f, c in zip(first[tri], count[tri]):
+                seen[f:f + c] += 1
+            assert (seen[:fs.n_tris] == 1).all(), name
+        finally:
+            oracle.free_flat(fs)
