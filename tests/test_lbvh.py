@@ -222,6 +222,10 @@ def test_repeated_device_builds_do_not_grow_gpu_memory(ra, gpu_ctx):
     d_tri = torch.from_numpy(scene.triangles.view(np.uint8).copy()).cuda()
     n = len(scene.triangles)
     small, _ = ra.Scene.builtin(0)
+    # warm-up: what the HIP runtime allocates once per process (kernel scratch, code objects,
+    # rocPRIM state) must not count as growth
+    gpu_ctx.build_device(None, 0, d_tri.data_ptr(), n, scene.materials)
+    gpu_ctx.build_device(None, 0, d_tri.data_ptr(), n // 16, scene.materials)
     gpu_ctx.upload(small)
     torch.cuda.synchronize()
     free_before = torch.cuda.mem_get_info()[0]
