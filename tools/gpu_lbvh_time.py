@@ -1,3 +1,5 @@
+"""Wall time of an LBVH upload (S1 level 8, S2 level 8) against the GPU time of the build: what the
+call costs besides its kernels.  usage: gpu_lbvh_time.py"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import rt_amd as ra
