@@ -509,10 +509,11 @@ def test_settings_fuzz(ra, oracle, gpu_ctx):
     four-wide nodes): frame sizes that are no multiple of anything, tile sizes, ranks,
     sample offsets, chunk sizes, depth, seed, tmin, lens, sky, accumulation onto a
     non-zero frame - GPU against oracle, bit for bit, counters included."""
-    rng = np.random.default_rng(2024)
+    # RT_FUZZ_SEED / RT_FUZZ_TRIALS: longer runs with other seeds outside the suite
+    rng = np.random.default_rng(int(os.environ.get("RT_FUZZ_SEED", "2024")))
     soup = _random_scene(ra, np.random.default_rng(9), 60, 80)
     scenes = [ra.Scene.builtin(0)[0], soup, ra.Scene.builtin(1, param=5)[0]]
-    for trial in range(48):
+    for trial in range(int(os.environ.get("RT_FUZZ_TRIALS", "48"))):
         scene = scenes[trial % 3]
         w, h = int(rng.integers(9, 140)), int(rng.integers(9, 90))
         world = int(rng.choice([1, 1, 2, 3, 5]))
@@ -539,4 +540,5 @@ def test_settings_fuzz(ra, oracle, gpu_ctx):
         assert np.array_equal(ia, ib), what
         assert_bit_equal(a, b, what)
         assert sa.as_dict() == sb, what
-        assert world == 1 or not owned.all()
+        n_tiles = -(-w // kw["tile_size"]) * -(-h // kw["tile_size"])
+        assert world == 1 or n_tiles < 2 or not owned.all()  # a one-tile frame belongs to one rank entirely
