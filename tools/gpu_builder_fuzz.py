@@ -1,7 +1,8 @@
 """Random scenes through the GPU builders, outside the suite: for every scene the GPU LBVH
 (host arrays and device arrays) must give the bytes of the oracle's restatement, its
 four-wide nodes must validate, a refit with moved primitives must give the bytes of the
-oracle's refit, and a small frame must match the oracle bit for bit.
+oracle's refit, and a small frame must match the oracle bit for bit; then the same refit
+and frame through the host SAH tree.
 usage: gpu_builder_fuzz.py [seed] [scenes]"""
 import ctypes as C
 import os, sys
@@ -69,6 +70,23 @@ for it in range(count):
     w_acc, w_ids, w_stats = o.render(after.c, cam, st, threads=8)
     ok = ok and np.array_equal(ids, w_ids) and np.array_equal(acc.view(np.uint32), w_acc.view(np.uint32)) and stats.as_dict() == w_stats
     o.free_flat(want); o.free_flat(want_r)
+    # the host SAH tree: refit and frame
+    ctx.upload(scene)
+    before = ctx.flat_scene()
+    rc, _ = o.validate_bvh(before.c)
+    ok = ok and rc == 0
+    want_r = o.refit(before.c, moved.desc)
+    ctx.refit(moved)
+    after = ctx.flat_scene()
+    d, e = _flat_bytes(after.c), _flat_bytes(want_r)
+    ok = ok and all(d[k] == e[k] for k in d)
+    if after.c.nodes4 and want_r.nodes4:
+        grab = lambda ptr, n: bytes((C.c_char * n).from_address(ptr))
+        ok = ok and grab(after.c.nodes4, after.c.n_nodes4 * 96) == grab(want_r.nodes4, want_r.n_nodes4 * 96)
+    acc, ids, stats = ctx.render(cam, st)
+    w_acc, w_ids, w_stats = o.render(after.c, cam, st, threads=8)
+    ok = ok and np.array_equal(ids, w_ids) and np.array_equal(acc.view(np.uint32), w_acc.view(np.uint32)) and stats.as_dict() == w_stats
+    o.free_flat(want_r)
     if not ok:
         bad += 1
         print("MISMATCH", what, flush=True)
