@@ -1,0 +1,149 @@
+"""BASELINE.json configs C3, C4 and C5 AT THEIR STATED SIZES, through the C ABI on the GPU.
+
+C3: S1 (1,310,722 triangles) at 1920x1080, 64 spp, depth 8.
+C4: S0 at 3840x2160, 256 spp, depth 8, tile-partitioned over 2 / 4 / 8 ranks (64x64 and
+    16x16 tiles), every rank's compact tile buffer placed where the gather puts it and
+    de-interleaved on the device.
+C5: S2 level 8 (10,485,760 triangles) at 1920x1080, 16 spp, depth 8, split over 8 ranks.
+
+Each case is checked three ways: (i) the whole frame at a sample count the oracle traces
+in a second or two, bit for bit, ids and traversal counters included, through BOTH
+builders; (ii) a crop of the frame at the STATED sample count, bit for bit; (iii)
+size-independent properties of the stated frame (sample counts, finiteness, no energy
+gain, rank partition == single-GPU frame, rays of the ranks add up, rerun identical).
+All ranks run on the one GPU of the box; RCCL itself is covered by tests/test_group.py
+(one-rank communicator) and the world-2 gloo test."""
+import numpy as np
+import pytest
+
+from util import assert_bit_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev_render(ra, ctx, cam, st, want_ids=True, stats=True):
+    """rtgpu_render_device into torch buffers -> (accum tensor [n,4], ids tensor or None, stats dict)."""
+    import torch
+    if st.flags & ra.FLAG_COMPACT:
+        n = ra.compact_pixels(st.width, st.height, st.tile_size, st.rank, st.world_size)
+    else:
+        n = st.width * st.height
+    acc = torch.zeros((n, 4), dtype=torch.float32, device="cuda")
+    ids = torch.full((n,), -1, dtype=torch.int32, device="cuda") if want_ids else None
+    s = ra.Stats()
+    ctx.render_device(cam, st, acc.data_ptr(), ids.data_ptr() if want_ids else None,
+                      torch.cuda.current_stream().cuda_stream, s if stats else None)
+    torch.cuda.synchronize()
+    return acc, ids, (s.as_dict() if stats else None)
+
+
+def _same_bits(a, b):
+    import torch
+    return torch.equal(a.view(torch.int32), b.view(torch.int32))
+
+
+def _partition_equals_full(ra, ctx, cam, st_full, full, full_ids, full_rays, world, tile):
+    """Every rank's compact frame, laid out as the gather leaves it on rank 0, untiled on
+    the device == the single-GPU frame."""
+    import torch
+    from rt_amd import dist as rdist
+    w, h = st_full.width, st_full.height
+    n_pad = rdist.padded_pixels(w, h, tile, world)
+    gathered = torch.zeros((world * n_pad, 4), dtype=torch.float32, device="cuda")
+    gathered_ids = torch.full((world * n_pad,), -1, dtype=torch.int32, device="cuda")
+    rays = 0
+    for r in range(world):
+        st = st_full.copy()
+        st.tile_size, st.rank, st.world_size, st.flags = tile, r, world, ra.FLAG_COMPACT
+        acc, ids, s = _dev_render(ra, ctx, cam, st)
+        gathered[r * n_pad:r * n_pad + acc.shape[0]] = acc
+        gathered_ids[r * n_pad:r * n_pad + ids.shape[0]] = ids
+        rays += s["rays"]
+    img = torch.zeros((h * w, 4), dtype=torch.float32, device="cuda")
+    img_ids = torch.zeros((h * w,), dtype=torch.int32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx.untile_device(gathered.data_ptr(), img.data_ptr(), w, h, tile, world, 16, stream)
+    ctx.untile_device(gathered_ids.data_ptr(), img_ids.data_ptr(), w, h, tile, world, 4, stream)
+    torch.cuda.synchronize()
+    assert rays == full_rays, (world, tile, rays, full_rays)
+    assert _same_bits(img, full), f"world {world}, {tile}x{tile} tiles: radiance differs from the 1-GPU frame"
+    assert torch.equal(img_ids, full_ids), f"world {world}, {tile}x{tile} tiles: ids differ"
+
+
+def _frame_properties(acc, spp, stats, w, h, depth):
+    import torch
+    assert stats["paths"] == w * h * spp and stats["paths"] <= stats["rays"] <= depth * stats["paths"]
+    assert bool(torch.all(acc[:, 3] == float(spp))) and bool(torch.isfinite(acc).all())
+    assert bool((acc[:, :3] >= 0).all()) and bool((acc[:, :3] <= spp * 1.0001).all())  # albedo <= 1, sky <= 1
+
+
+def _whole_frame_vs_oracle(ra, oracle, ctx, scene, cam, w, h, spp, builders=("sah", "lbvh")):
+    for builder in builders:
+        ctx.upload(scene, builder=builder)
+        st = ra.default_settings(w, h, spp=spp, max_depth=8, flags=ra.FLAG_STATS)
+        acc, ids, s = _dev_render(ra, ctx, cam, st)
+        st_o = ra.default_settings(w, h, spp=spp, max_depth=8)
+        b, ib, sb = oracle.render(ctx.flat_scene().c, cam, st_o, threads=16)
+        assert np.array_equal(ids.cpu().numpy().view(np.uint32).reshape(h, w), ib), builder
+        assert_bit_equal(acc.cpu().numpy().reshape(h, w, 4), b, f"whole frame / {builder}")
+        assert s == sb, (builder, s, sb)
+
+
+def _crop_vs_oracle(ra, oracle, ctx, cam, st, acc, ids, crop):
+    w, h = st.width, st.height
+    x0, y0, x1, y1 = crop
+    b, ib, _ = oracle.render(ctx.flat_scene().c, cam, st, crop=crop, threads=16)
+    a = acc.view(h, w, 4)[y0:y1, x0:x1].cpu().numpy()
+    i = ids.view(h, w)[y0:y1, x0:x1].cpu().numpy().view(np.uint32)
+    assert np.array_equal(i, ib[y0:y1, x0:x1])
+    assert_bit_equal(a, b[y0:y1, x0:x1], f"crop {crop} at {st.spp} spp")
+    return i
+
+
+def test_c3_as_stated(ra, oracle, gpu_ctx):
+    """C3: ~1M-triangle mesh, 1920x1080, 64 spp on one GPU."""
+    w, h = 1920, 1080
+    scene, cam = ra.Scene.builtin(1, param=8, aspect=w / h)
+    assert len(scene.triangles) == 1310722
+    _whole_frame_vs_oracle(ra, oracle, gpu_ctx, scene, cam, w, h, 4)
+    gpu_ctx.upload(scene)  # the SAH tree, as the bench uses it
+    st = ra.default_settings(w, h, spp=64, max_depth=8)
+    acc, ids, s = _dev_render(ra, gpu_ctx, cam, st)
+    _frame_properties(acc, 64, s, w, h, 8)
+    hit = _crop_vs_oracle(ra, oracle, gpu_ctx, cam, st, acc, ids, (880, 470, 1040, 560))
+    assert (hit != ra.NO_HIT).all()                      # the crop lies on the mesh
+    _crop_vs_oracle(ra, oracle, gpu_ctx, cam, st, acc, ids, (0, 0, 96, 48))  # ground quad / sky corner
+    acc2, ids2, s2 = _dev_render(ra, gpu_ctx, cam, st)
+    assert _same_bits(acc, acc2) and s2 == s             # schedule independent
+
+
+def test_c4_as_stated_tile_partition(ra, oracle, gpu_ctx):
+    """C4: S0 at 3840x2160, 256 spp, tile-partitioned over 2 / 4 / 8 ranks."""
+    w, h = 3840, 2160
+    scene, cam = ra.Scene.builtin(0, aspect=w / h)
+    _whole_frame_vs_oracle(ra, oracle, gpu_ctx, scene, cam, w, h, 2)
+    gpu_ctx.upload(scene)
+    st = ra.default_settings(w, h, spp=256, max_depth=8)
+    full, full_ids, s = _dev_render(ra, gpu_ctx, cam, st)
+    _frame_properties(full, 256, s, w, h, 8)
+    _crop_vs_oracle(ra, oracle, gpu_ctx, cam, st, full, full_ids, (1900, 1000, 1964, 1024))
+    for tile in (64, 16):
+        for world in (2, 4, 8):
+            _partition_equals_full(ra, gpu_ctx, cam, st, full, full_ids, s["rays"], world, tile)
+
+
+def test_c5_as_stated(ra, oracle, gpu_ctx):
+    """C5: ~10M-triangle procedural scene, 8 bounces, 1920x1080, 16 spp per frame, over 8 ranks."""
+    w, h = 1920, 1080
+    scene, cam = ra.Scene.builtin(2, param=8, aspect=w / h)
+    assert len(scene.triangles) == 10485760
+    _whole_frame_vs_oracle(ra, oracle, gpu_ctx, scene, cam, w, h, 2)
+    gpu_ctx.upload(scene)
+    st = ra.default_settings(w, h, spp=16, max_depth=8)
+    full, full_ids, s = _dev_render(ra, gpu_ctx, cam, st)
+    _frame_properties(full, 16, s, w, h, 8)
+    assert s["rays"] > 2 * s["paths"]                    # incoherent secondary rays are there
+    _crop_vs_oracle(ra, oracle, gpu_ctx, cam, st, full, full_ids, (900, 500, 1028, 564))
+    _partition_equals_full(ra, gpu_ctx, cam, st, full, full_ids, s["rays"], 8, 64)
+    _partition_equals_full(ra, gpu_ctx, cam, st, full, full_ids, s["rays"], 8, 16)
+    gpu_ctx.upload(ra.Scene.builtin(0)[0])               # give the 2 GB of scene arrays back
