@@ -152,7 +152,8 @@ typedef struct rtgpu_flat_scene {
   const void    *nodes48;      /* n_nodes packed nodes of 48 B (rtgpu_format.h) when
                                   n_nodes >= RTGPU_NODE48_MIN_NODES, else NULL: the
                                   array the trace loop traverses when nodes4 is
-                                  absent (after a refit)                          */
+                                  absent (RTGPU_NO_WIDE, or a four-wide stack that
+                                  does not fit); a refit refreshes both           */
   const void    *nodes4;       /* n_nodes4 four-wide packed nodes of 96 B, same
                                   threshold; traversed in preference when present  */
   uint64_t       n_nodes4;
@@ -250,7 +251,13 @@ int  rtgpu_render_end(rtgpu_ctx *ctx, rtgpu_stats *stats /* may be NULL */);
 
 /* As rtgpu_render, outputs in device memory of the context's GPU, launched on `stream`
  * (a hipStream_t, NULL = default stream).  Asynchronous unless `stats` is
- * non-NULL (then it synchronises the stream to read the counters back). */
+ * non-NULL (then it synchronises the stream to read the counters back).
+ * Stream rule: every launch of a context uses the context's one set of scratch buffers
+ * (work-queue head, counters, overflow stacks, chunk planes).  The library orders launches
+ * itself: a call on a stream other than the previous call's first makes that stream wait
+ * (hipStreamWaitEvent) for the end of the previous launch, so frames queued on different
+ * streams run one after the other, never together.  What stays the caller's job is the
+ * order between a frame and the caller's OWN work on the output buffers. */
 int  rtgpu_render_device(rtgpu_ctx *ctx, const rtgpu_camera *cam, const rtgpu_settings *s,
                          void *d_accum_rgba, void *d_prim_id, void *stream,
                          rtgpu_stats *stats);
@@ -258,6 +265,10 @@ int  rtgpu_render_device(rtgpu_ctx *ctx, const rtgpu_camera *cam, const rtgpu_se
 /* Duration of the trace kernel of the last render call on this context,
  * measured with HIP events on the stream the kernel ran on.  Synchronises. */
 int  rtgpu_last_kernel_ms(rtgpu_ctx *ctx, float *ms);
+/* Name of the trace-kernel instantiation that launch used, as a profiler prints it:
+ * "trace_kernel<STATS,REFILL,MODE>" (MODE: DESIGN.md §4.1); "" before the first launch.
+ * The string lives in the context. */
+const char *rtgpu_last_kernel_name(const rtgpu_ctx *ctx);
 
 /* Diagnostics: raw counters of the last launch on this context.  out[0] queue
  * head, [1..6] as rtgpu_stats, and with RTGPU_FLAG_PROFILE [7..15] = per-WAVE
@@ -266,7 +277,8 @@ int  rtgpu_last_kernel_ms(rtgpu_ctx *ctx, float *ms);
  * rounds, lanes in traversal rounds}: lane totals / (64 x wave counts) is the
  * SIMD lane utilisation of each section; [16..20] = shader-clock cycles summed
  * over waves spent in {shading, work-item bookkeeping, camera rays, traversal
- * set-up, traversal}; [21..31] zero.  Synchronises the device. */
+ * set-up, traversal}; [21], [22] = the node-phase and leaf-phase cycles inside the
+ * traversal figure; [23..31] zero.  Synchronises the device. */
 int  rtgpu_profile_counters(rtgpu_ctx *ctx, uint64_t out[32]);
 
 /* accum (float4 sums) -> 0xRRGGBBAA, gamma 2, like RTIOW's write_color.

@@ -146,6 +146,8 @@ lib.rtgpu_render_device.argtypes = [
     C.c_void_p, _P(Camera), _P(Settings), C.c_void_p, C.c_void_p, C.c_void_p, _P(Stats)]
 lib.rtgpu_profile_counters.argtypes = [C.c_void_p, _P(C.c_uint64)]
 lib.rtgpu_last_kernel_ms.argtypes = [C.c_void_p, _P(C.c_float)]
+lib.rtgpu_last_kernel_name.argtypes = [C.c_void_p]
+lib.rtgpu_last_kernel_name.restype = C.c_char_p
 lib.rtgpu_resolve_rgba8_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
 lib.rtgpu_resolve_rgba8.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
 lib.rtgpu_compact_pixels.argtypes = [C.c_uint32] * 5
@@ -450,6 +452,10 @@ class Context:
         ms = C.c_float()
         self._check(lib.rtgpu_last_kernel_ms(self._h, C.byref(ms)))
         return float(ms.value)
+
+    def kernel_name(self):
+        """Instantiation of the last trace-kernel launch, e.g. 'trace_kernel<0,16,2>'."""
+        return (lib.rtgpu_last_kernel_name(self._h) or b"").decode()
 
     def resolve(self, accum):
         accum = np.ascontiguousarray(accum, np.float32)

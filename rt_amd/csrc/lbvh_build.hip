@@ -366,6 +366,8 @@ namespace rtgpu {
     hipError_t e_ = (call);                                                           \
     if (e_ != hipSuccess) {                                                           \
       err = std::string("lbvh: " #call ": ") + hipGetErrorString(e_);                 \
+      if (ev0) (void)hipEventDestroy(ev0);                                            \
+      if (ev1) (void)hipEventDestroy(ev1);                                            \
       free_lbvh(out, pool);                                                                 \
       return 2;                                                                       \
     }                                                                                 \
@@ -530,7 +532,13 @@ int lbvh_build_device_ptrs(const rtgpu_scene_desc *scene, const void *d_spheres_
     uint32_t left = (uint32_t)n_inner, pass = 0;
     const unsigned fit_blocks = std::min<unsigned>((unsigned)(((size_t)n_inner + kFitThreads - 1) / kFitThreads), 2048u);
     while (left != 0u) {
-      if (pass >= 64u) { err = "internal: lbvh fit did not finish in 64 level passes"; free_lbvh(out, pool); return 3; }
+      if (pass >= 64u) {
+        err = "internal: lbvh fit did not finish in 64 level passes";
+        (void)hipEventDestroy(ev0);
+        (void)hipEventDestroy(ev1);
+        free_lbvh(out, pool);
+        return 3;
+      }
       for (int k = 0; k < 8; k++) {
         pass++;
         const uint32_t *lin = (pass & 1u) ? d_list_b : d_list_a;   // pass 1 reads no list

@@ -222,7 +222,7 @@ __global__ __launch_bounds__(kThreads) void check_prims(const rtgpu_sphere *sph,
 }
 
 int check_prims_device(const void *d_sph_in, uint32_t ns, const void *d_tri_in, uint32_t nt, uint32_t n_materials,
-                       uint32_t *d_flag, std::string &err) {
+                       uint32_t *d_flag, std::string &err, const char *who) {
   if (ns + nt == 0) return 0;
   uint32_t *d_bad = d_flag, bad = 0;
   hipError_t e = d_flag ? hipSuccess : hipMalloc((void **)&d_bad, sizeof(uint32_t));
@@ -235,8 +235,8 @@ int check_prims_device(const void *d_sph_in, uint32_t ns, const void *d_tri_in, 
   }
   if (e == hipSuccess) e = hipMemcpy(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost);
   if (!d_flag) (void)hipFree(d_bad);
-  if (e != hipSuccess) { err = std::string("refit: input check: ") + hipGetErrorString(e); return 2; }
-  if (bad) { err = "refit: a primitive has a non-finite coordinate, a non-positive radius or a material index out of range"; return 1; }
+  if (e != hipSuccess) { err = std::string(who) + ": input check: " + hipGetErrorString(e); return 2; }
+  if (bad) { err = std::string(who) + ": a primitive has a non-finite coordinate, a non-positive radius or a material index out of range"; return 1; }
   return 0;
 }
 

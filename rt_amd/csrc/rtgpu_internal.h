@@ -63,7 +63,7 @@ int  refit_device_ptrs(const void *d_spheres, uint32_t ns, const void *d_triangl
                        uint64_t n_nodes, void *d_tris, void *d_sphs, void *d_sph_meta, uint32_t *ws, double *gpu_ms,
                        std::string &err);
 int  check_prims_device(const void *d_spheres, uint32_t ns, const void *d_triangles, uint32_t nt, uint32_t n_materials,
-                        uint32_t *d_flag, std::string &err);
+                        uint32_t *d_flag, std::string &err, const char *who /* "refit" or "build": prefix of the message */);
 
 // host_util.cpp
 void set_global_error(const std::string &msg);

@@ -1042,6 +1042,15 @@ struct rtgpu_ctx {
   unsigned long long *d_counters = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
+  // Every launch shares the context's scratch (queue head and counters, overflow stacks, chunk
+  // planes, ev0 / ev1), and rtgpu_render_device is asynchronous on any stream the caller
+  // names: ev_last marks the end of the last launch's work (trace + combine) and a launch on
+  // ANOTHER stream waits for it first, so two frames never run on the scratch at once.
+  unsigned long long *last_counters = nullptr;  // where the last launch kept its counters (own buffer or static scratch)
+  char kernel_name[48] = "";  // instantiation of the last launch, as rocprofv3 prints it
+  hipEvent_t ev_last = nullptr;
+  hipStream_t last_stream = nullptr;
+  bool have_last = false;
   int num_cus = 0;
   int variant = 0;              // index into kVariants (refill threshold), see rtgpu_create
   int stack_lds = kStackLds;    // cap on LDS stack entries (RTGPU_STACK_LDS shrinks it for tests)
@@ -1166,6 +1175,7 @@ extern "C" int rtgpu_create(rtgpu_ctx **out, int device_index) {
       (e = hipGetDeviceProperties(&prop, device_index)) != hipSuccess ||
       (e = hipMalloc((void **)&ctx->d_counters, 256)) != hipSuccess ||
       (e = hipEventCreate(&ctx->ev0)) != hipSuccess || (e = hipEventCreate(&ctx->ev1)) != hipSuccess ||
+      (e = hipEventCreateWithFlags(&ctx->ev_last, hipEventDisableTiming)) != hipSuccess ||
       (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
       (e = hipEventCreateWithFlags(&ctx->ev_done, hipEventDisableTiming)) != hipSuccess) {
     rtgpu::set_global_error(std::string("rtgpu_create: ") + hipGetErrorString(e));
@@ -1232,6 +1242,7 @@ extern "C" void rtgpu_destroy(rtgpu_ctx *ctx) {
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->ev_done) (void)hipEventDestroy(ctx->ev_done);
+  if (ctx->ev_last) (void)hipEventDestroy(ctx->ev_last);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -1307,7 +1318,7 @@ extern "C" int rtgpu_build_device(rtgpu_ctx *ctx, const void *d_spheres, uint64_
   if (rtgpu::validate_scene(&scene, ctx->err)) return 1;  // the material table
   // what validate_scene checks for primitives on the host, on the device
   if (int rc = rtgpu::check_prims_device(d_spheres, (uint32_t)n_spheres, d_triangles, (uint32_t)n_triangles,
-                                         (uint32_t)std::min<uint64_t>(n_materials, 0xFFFFFFFFull), nullptr, ctx->err))
+                                         (uint32_t)std::min<uint64_t>(n_materials, 0xFFFFFFFFull), nullptr, ctx->err, "build"))
     return rc;
   scene.n_spheres = n_spheres;
   scene.n_triangles = n_triangles;
@@ -1438,7 +1449,7 @@ extern "C" int rtgpu_refit_device(rtgpu_ctx *ctx, const void *d_spheres, uint64_
   uint32_t *flag = ctx->d_refit_ws + rtgpu::refit_workspace_words(h.n_nodes) - 1;  // last word: the checks' and packers' flag
   // what validate_scene checks on the host, before anything is rewritten
   if (int rc = rtgpu::check_prims_device(d_spheres, (uint32_t)n_spheres, d_triangles, (uint32_t)n_triangles,
-                                         (uint32_t)h.n_materials, flag, ctx->err))
+                                         (uint32_t)h.n_materials, flag, ctx->err, "refit"))
     return rc;
   ctx->host_stale = true;
   double ms = 0.0;
@@ -1457,7 +1468,8 @@ extern "C" int rtgpu_refit_device(rtgpu_ctx *ctx, const void *d_spheres, uint64_
 }
 
 extern "C" int rtgpu_get_flat_scene(const rtgpu_ctx *ctx, rtgpu_flat_scene *out) {
-  if (!ctx || !out || !ctx->have_scene) return 1;
+  if (!ctx || !out) return 1;
+  if (!ctx->have_scene) { const_cast<rtgpu_ctx *>(ctx)->err = "no scene uploaded (call rtgpu_upload_scene first)"; return 1; }
   if (ctx->host_stale) {
     // arrays a GPU build has not copied back yet are allocated here (with the zeroed tail
     // records of flatten_scene); the context stays logically const
@@ -1478,9 +1490,12 @@ extern "C" int rtgpu_get_flat_scene(const rtgpu_ctx *ctx, rtgpu_flat_scene *out)
       h.nodes4 = want(h.nodes4, (size_t)h.n_nodes4 * sizeof(rtgpu_node4));
       h.nodes4_src = (const uint32_t *)want(h.nodes4_src, (size_t)h.n_nodes4 * 16);
     }
+    std::string &msg = const_cast<rtgpu_ctx *>(ctx)->err;
     if (!h.nodes || !h.tris || !h.spheres || !h.sphere_meta || (ctx->d_nodes48 && !h.nodes48) ||
-        (ctx->d_nodes4 && (!h.nodes4 || !h.nodes4_src)))
+        (ctx->d_nodes4 && (!h.nodes4 || !h.nodes4_src))) {
+      msg = "rtgpu_get_flat_scene: out of host memory for the copy of the flattened scene";
       return 2;
+    }
     if (hipSetDevice(ctx->device) != hipSuccess ||
         hipMemcpy((void *)h.nodes, ctx->d_nodes, (size_t)h.n_nodes * sizeof(rtgpu_node), hipMemcpyDeviceToHost) != hipSuccess ||
         hipMemcpy((void *)h.tris, ctx->d_tris, (size_t)h.n_tris * sizeof(rtgpu_tri), hipMemcpyDeviceToHost) != hipSuccess ||
@@ -1488,23 +1503,49 @@ extern "C" int rtgpu_get_flat_scene(const rtgpu_ctx *ctx, rtgpu_flat_scene *out)
         hipMemcpy((void *)h.sphere_meta, ctx->d_sph_meta, (size_t)h.n_spheres * 2 * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess ||
         (h.nodes48 && hipMemcpy((void *)h.nodes48, ctx->d_nodes48, (size_t)h.n_nodes * sizeof(rtgpu_node48), hipMemcpyDeviceToHost) != hipSuccess) ||
         (h.nodes4 && (hipMemcpy((void *)h.nodes4, ctx->d_nodes4, (size_t)h.n_nodes4 * sizeof(rtgpu_node4), hipMemcpyDeviceToHost) != hipSuccess ||
-                      hipMemcpy((void *)h.nodes4_src, ctx->d_nodes4_src, (size_t)h.n_nodes4 * 16, hipMemcpyDeviceToHost) != hipSuccess)))
+                      hipMemcpy((void *)h.nodes4_src, ctx->d_nodes4_src, (size_t)h.n_nodes4 * 16, hipMemcpyDeviceToHost) != hipSuccess))) {
+      msg = std::string("rtgpu_get_flat_scene: copying the flattened scene back failed: ") + hipGetErrorString(hipGetLastError());
       return 2;
+    }
     ctx->host_stale = false;
   }
   *out = ctx->host;
   return 0;
 }
 
+namespace {
+// Device scratch of one launch.  The context's own buffers (grown on demand) for the ordinary
+// entry points; the static array of this GPU for rtgpu_render_device_static, which may not
+// allocate: then planes_cap is a hard limit and there is no overflow stack.
+struct LaunchScratch {
+  unsigned long long *counters;
+  float4 *planes;          // NULL with planes_cap == 0: take (and grow) the context's
+  size_t planes_cap;
+  bool may_allocate;
+};
+
+int launch_frame(rtgpu_ctx *ctx, const rtgpu_camera *cam, const rtgpu_settings *s, void *d_accum_rgba, void *d_prim_id,
+                 void *stream_, rtgpu_stats *stats, LaunchScratch sc);
+}  // namespace
+
 extern "C" int rtgpu_render_device(rtgpu_ctx *ctx, const rtgpu_camera *cam, const rtgpu_settings *s,
                                    void *d_accum_rgba, void *d_prim_id, void *stream_,
                                    rtgpu_stats *stats) {
   if (!ctx) return 1;
+  return launch_frame(ctx, cam, s, d_accum_rgba, d_prim_id, stream_, stats, LaunchScratch{ctx->d_counters, nullptr, 0, true});
+}
+
+namespace {
+int launch_frame(rtgpu_ctx *ctx, const rtgpu_camera *cam, const rtgpu_settings *s, void *d_accum_rgba, void *d_prim_id,
+                 void *stream_, rtgpu_stats *stats, LaunchScratch sc) {
   uint32_t ts_log2 = 0;
   if (check_settings(ctx, cam, s, &ts_log2)) return 1;
   if (!d_accum_rgba) { ctx->err = "accum output pointer is NULL"; return 1; }
   hipStream_t stream = (hipStream_t)stream_;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  ctx->last_counters = sc.counters;
+  // the previous launch ran on another stream: order this one after it (see ev_last)
+  if (ctx->have_last && ctx->last_stream != stream) HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->ev_last, 0));
 
   rtgpu::TileGrid g = rtgpu::tile_grid(s->width, s->height, s->tile_size);
   uint64_t local_tiles = rtgpu::rank_tiles(g.n_tiles, s->rank, s->world_size);
@@ -1513,10 +1554,21 @@ extern "C" int rtgpu_render_device(rtgpu_ctx *ctx, const rtgpu_camera *cam, cons
   uint64_t n_items = n_px_items * n_chunks;
   if (n_items >= 0xFFFFFFFFull) { ctx->err = "frame too large for one launch (>= 2^32 work items)"; return 1; }
   uint64_t n_px_out = (s->flags & RTGPU_FLAG_COMPACT) ? n_px_items : (uint64_t)s->width * s->height;
-  if (n_chunks > 1 && n_px_out > 0) {
+  float4 *planes = sc.planes;
+  if (n_chunks > 1 && n_px_out > 0 && !sc.may_allocate) {
+    if ((uint64_t)n_chunks * n_px_out * sizeof(float4) > (uint64_t)sc.planes_cap) {
+      char msg[256];
+      std::snprintf(msg, sizeof(msg), "rtgpu_render_device_static: %u chunks x %llu pixels x 16 B of chunk planes exceed the "
+                    "static scratch of %llu bytes (use chunk_samples >= spp for one chunk, fewer chunks, or a smaller frame)",
+                    n_chunks, (unsigned long long)n_px_out, (unsigned long long)sc.planes_cap);
+      ctx->err = msg;
+      return 1;
+    }
+  }
+  if (n_chunks > 1 && n_px_out > 0 && sc.may_allocate) {
     size_t want = (size_t)n_chunks * n_px_out * sizeof(float4);
     if (ctx->planes_bytes < want) {  // grow-only
-      HIP_TRY(ctx, hipStreamSynchronize(stream));
+      HIP_TRY(ctx, hipStreamSynchronize(stream));  // (which, after the wait above, covers the last launch on any stream)
       (void)hipFree(ctx->d_planes);
       ctx->d_planes = nullptr;
       ctx->planes_bytes = 0;
@@ -1526,6 +1578,7 @@ extern "C" int rtgpu_render_device(rtgpu_ctx *ctx, const rtgpu_camera *cam, cons
       ctx->planes_bytes = want;
     }
   }
+  if (sc.may_allocate) planes = ctx->d_planes;
 
   KParams P;
   std::memset(&P, 0, sizeof(P));
@@ -1541,7 +1594,7 @@ extern "C" int rtgpu_render_device(rtgpu_ctx *ctx, const rtgpu_camera *cam, cons
   P.mats = (const float4 *)ctx->d_mats;
   P.accum = (float4 *)d_accum_rgba;
   P.prim_id = (uint32_t *)d_prim_id;
-  P.counters = ctx->d_counters;
+  P.counters = sc.counters;
   P.ovf_stack = ctx->d_ovf;
   P.wave_times = ctx->d_wave_times;
   for (int k = 0; k < 3; k++) {
@@ -1558,7 +1611,7 @@ extern "C" int rtgpu_render_device(rtgpu_ctx *ctx, const rtgpu_camera *cam, cons
   P.max_depth = s->max_depth; P.seed = s->seed;
   P.ts_log2 = ts_log2; P.tiles_x = g.tiles_x; P.rank = s->rank; P.world = s->world_size;
   P.n_items = (uint32_t)n_items; P.flags = s->flags;
-  P.planes = ctx->d_planes;
+  P.planes = planes;
   P.chunk_samples = s->chunk_samples; P.n_chunks = n_chunks; P.plane_stride = (uint32_t)n_px_out;
   P.groups_small = (n_items >> 6) < (1ull << 22) ? 1u : 0u;
   P.inv_n_chunks = 1.0f / (float)n_chunks;
@@ -1575,6 +1628,10 @@ extern "C" int rtgpu_render_device(rtgpu_ctx *ctx, const rtgpu_camera *cam, cons
   if (stack_lds > stack_fit) stack_lds = stack_fit;
   P.stack_lds = stack_lds;
   P.stack_lds_only = need <= stack_lds ? 1u : 0u;
+  if (!sc.may_allocate && !P.stack_lds_only) {
+    ctx->err = "rtgpu_render_device_static: the tree is too deep for traversal stacks in LDS alone (the overflow stack is not part of the static scratch)";
+    return 1;
+  }
   // small scenes: the whole tree in LDS with planes kSmallNodes apart (MODE 2); larger
   // trees are fetched through L1 (a partial cache measured no gain)
   const size_t stack_bytes = (size_t)stack_lds * kBlock * sizeof(uint32_t);
@@ -1593,7 +1650,7 @@ extern "C" int rtgpu_render_device(rtgpu_ctx *ctx, const rtgpu_camera *cam, cons
   }
 
   bool want_stats = (s->flags & (RTGPU_FLAG_STATS | RTGPU_FLAG_PROFILE)) != 0;
-  HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 256, stream));
+  HIP_TRY(ctx, hipMemsetAsync(sc.counters, 0, 256, stream));
   ctx->timed = false;
   if (n_items > 0) {
     uint64_t want = (n_items + kBlock - 1) / kBlock;
@@ -1603,7 +1660,9 @@ extern "C" int rtgpu_render_device(rtgpu_ctx *ctx, const rtgpu_camera *cam, cons
     const Variant &var = kVariants[ctx->variant >= 0 ? ctx->variant : (mode == 2 ? kVariantSmallTree : kVariantLargeTree)];
     static_assert(RTGPU_NODE48_MIN_NODES > (unsigned)kSmallNodes, "a packed tree must not fit the LDS node cache");
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
-    KernelFn fn = var.fn[(s->flags & RTGPU_FLAG_PROFILE) ? 2 : want_stats ? 1 : 0][mode];
+    const int inst = (s->flags & RTGPU_FLAG_PROFILE) ? 2 : want_stats ? 1 : 0;
+    KernelFn fn = var.fn[inst][mode];
+    std::snprintf(ctx->kernel_name, sizeof(ctx->kernel_name), "trace_kernel<%d,%d,%d>", inst, var.refill, mode);
     hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), lds_bytes, stream, P);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev1, stream));
@@ -1611,7 +1670,7 @@ extern "C" int rtgpu_render_device(rtgpu_ctx *ctx, const rtgpu_camera *cam, cons
     if (n_chunks > 1) {
       uint64_t blocks = (n_px_out + 255) / 256;
       unsigned cgrid = (unsigned)(blocks < 4096 ? blocks : 4096);
-      hipLaunchKernelGGL(combine_kernel, dim3(cgrid), dim3(256), 0, stream, (const float4 *)ctx->d_planes,
+      hipLaunchKernelGGL(combine_kernel, dim3(cgrid), dim3(256), 0, stream, (const float4 *)planes,
                          (float4 *)d_accum_rgba, n_px_out, n_chunks, n_px_out, (float)s->spp,
                          (uint32_t)((s->flags & RTGPU_FLAG_ACCUMULATE) ? 1u : 0u),
                          CombineGeom{s->width, s->height, ts_log2, g.tiles_x, s->rank, s->world_size,
@@ -1619,21 +1678,25 @@ extern "C" int rtgpu_render_device(rtgpu_ctx *ctx, const rtgpu_camera *cam, cons
       HIP_TRY(ctx, hipGetLastError());
     }
   }
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_last, stream));
+  ctx->last_stream = stream;
+  ctx->have_last = true;
   if (stats) {
     unsigned long long c[8];
     HIP_TRY(ctx, hipStreamSynchronize(stream));
-    HIP_TRY(ctx, hipMemcpy(c, ctx->d_counters, sizeof(c), hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(c, sc.counters, sizeof(c), hipMemcpyDeviceToHost));
     stats->paths = c[1]; stats->rays = c[2]; stats->nodes = c[3];
     stats->tri_tests = c[4]; stats->sphere_tests = c[5]; stats->scatters = c[6];
   }
   return 0;
 }
+}  // namespace
 
 extern "C" int rtgpu_profile_counters(rtgpu_ctx *ctx, uint64_t out[32]) {
   if (!ctx || !out) return 1;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipDeviceSynchronize());
-  HIP_TRY(ctx, hipMemcpy(out, ctx->d_counters, 256, hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpy(out, ctx->last_counters ? ctx->last_counters : ctx->d_counters, 256, hipMemcpyDeviceToHost));
   return 0;
 }
 
@@ -1697,6 +1760,8 @@ extern "C" int rtgpu_debug_wave_times(rtgpu_ctx *ctx, uint64_t *out, uint64_t ma
   *n_waves = n;
   return 0;
 }
+
+extern "C" const char *rtgpu_last_kernel_name(const rtgpu_ctx *ctx) { return ctx ? ctx->kernel_name : ""; }
 
 extern "C" int rtgpu_last_kernel_ms(rtgpu_ctx *ctx, float *ms) {
   if (!ctx || !ms) return 1;

@@ -378,6 +378,34 @@ def test_device_pointer_entry_point_and_resolve(ra, oracle, gpu_ctx):
     assert np.all((want & 0xFF) == 0xFF)
 
 
+def test_launches_on_different_streams_are_ordered(ra, oracle, gpu_ctx):
+    """Every launch of a context shares its scratch (queue head, chunk planes, stacks).  A frame
+    queued with rtgpu_render_device on a non-blocking stream followed AT ONCE by a frame on
+    another stream (here rtgpu_render's null stream, which does not wait for non-blocking
+    streams by itself) must both come out bit-exact: the library orders them with an event."""
+    import torch
+    w, h = 640, 360
+    scene, cam = ra.Scene.builtin(0, aspect=w / h)
+    gpu_ctx.upload(scene)
+    st_a = ra.default_settings(w, h, spp=32, max_depth=8)             # ~3 ms of kernel: still running
+    st_b = ra.default_settings(w, h, spp=8, max_depth=8, seed=5)      # when the second call arrives
+    want_a, _, _ = oracle.render(gpu_ctx.flat_scene().c, cam, st_a, threads=16, want_ids=False)
+    want_b, _, _ = oracle.render(gpu_ctx.flat_scene().c, cam, st_b, threads=16, want_ids=False)
+    side = torch.cuda.Stream()                                        # torch side streams are non-blocking
+    other = torch.cuda.Stream()
+    for _ in range(3):
+        acc_a = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+        acc_c = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        gpu_ctx.render_device(cam, st_a, acc_a.data_ptr(), None, side.cuda_stream)
+        got_b, _, _ = gpu_ctx.render(cam, st_b, want_ids=False)       # null stream, blocking
+        gpu_ctx.render_device(cam, st_a, acc_c.data_ptr(), None, other.cuda_stream)
+        torch.cuda.synchronize()
+        assert_bit_equal(got_b, want_b, "null-stream frame behind a side-stream frame")
+        assert_bit_equal(acc_a.cpu().numpy(), want_a, "side-stream frame")
+        assert_bit_equal(acc_c.cpu().numpy(), want_a, "third stream")
+
+
 def test_error_paths(ra, gpu_ctx):
     scene, cam = ra.Scene.builtin(0)
     gpu_ctx.upload(scene)

@@ -13,8 +13,9 @@ from util import bits, make_scene
 MATS = [(0, .5, .5, .5, 0), (1, .8, .8, .8, 0.1), (2, 1, 1, 1, 1.5)]
 
 
-def _flat_bytes(c):
-    """The arrays of a flattened scene as bytes, tails included."""
+def _flat_bytes(c, wide=False):
+    """The arrays of a flattened scene as bytes, tails included (wide: and the four-wide nodes,
+    which the restatement of the builder does not make - they are compared GPU against GPU)."""
     def grab(ptr, n):
         return bytes((C.c_char * n).from_address(ptr)) if n else b""
     return {
@@ -24,6 +25,10 @@ def _flat_bytes(c):
         "meta": grab(c.sphere_meta, (c.n_spheres * 2 + 16) * 4),
         "materials": grab(c.materials, c.n_materials * 32),
         "nodes48": grab(c.nodes48, c.n_nodes * 48) if c.nodes48 else b"",
+        **({} if not wide else {
+        # numbered from a scan in thread order (collapse4.hip): the same bytes on every run
+        "nodes4": grab(c.nodes4, c.n_nodes4 * 96) if c.nodes4 else b"",
+        "nodes4_src": grab(c.nodes4_src, c.n_nodes4 * 16) if c.nodes4_src else b""}),
     }
 
 
@@ -158,6 +163,34 @@ def test_four_wide_nodes_collapsed_on_the_gpu(ra, oracle, gpu_ctx):
 
 
 @pytest.mark.gpu
+def test_gpu_built_tree_is_reproducible(ra, gpu_ctx):
+    """The four-wide nodes of a GPU-built tree carry their child numbers in the low bytes of box
+    planes, so the numbering reaches the traversal order and the counters.  It comes from a scan
+    in thread order: the same scene gives the same bytes twice on one context and on a fresh
+    one (what N ranks that each build their own tree rely on), and the same counters."""
+    if os.environ.get("RTGPU_NO_WIDE"):
+        pytest.skip("asserts the four-wide nodes that RTGPU_NO_WIDE switches off")
+    scene, cam = ra.Scene.builtin(2, param=5, aspect=16 / 9)   # 8 x 20k triangles: ~100k four-wide nodes
+    st = ra.default_settings(160, 90, spp=2, max_depth=8, flags=ra.FLAG_STATS)
+    runs = []
+    fresh = ra.Context(0)
+    try:
+        for ctx in (gpu_ctx, gpu_ctx, fresh):
+            ctx.upload(scene, builder="lbvh")
+            fs = ctx.flat_scene()
+            assert fs.c.nodes4 and fs.c.n_nodes4 > 10000
+            acc, ids, stats = ctx.render(cam, st)
+            runs.append((_flat_bytes(fs.c, wide=True), bits(acc).copy(), ids.copy(), stats.as_dict()))
+    finally:
+        fresh.close()
+    for other in runs[1:]:
+        for k in runs[0][0]:
+            assert other[0][k] == runs[0][0][k], f"{k} differ between two builds of one scene"
+        assert np.array_equal(other[1], runs[0][1]) and np.array_equal(other[2], runs[0][2])
+        assert other[3] == runs[0][3]
+
+
+@pytest.mark.gpu
 def test_build_from_device_arrays(ra, oracle, gpu_ctx):
     """rtgpu_build_device: the tree over primitive arrays in GPU memory is byte for byte the
     tree rtgpu_upload_scene_lbvh builds from the same arrays on the host; bad input is found
@@ -167,14 +200,14 @@ def test_build_from_device_arrays(ra, oracle, gpu_ctx):
         scene = _scenes(ra)[name]
         gpu_ctx.upload(scene, builder="lbvh")
         want_fs = gpu_ctx.flat_scene()
-        want = _flat_bytes(want_fs.c)
+        want = _flat_bytes(want_fs.c, wide=True)
         want_counts = (want_fs.c.n_nodes, want_fs.c.max_depth, want_fs.c.n_nodes4, want_fs.c.max_stack4)
         d_sph = torch.from_numpy(scene.spheres.view(np.uint8).copy()).cuda() if len(scene.spheres) else None
         d_tri = torch.from_numpy(scene.triangles.view(np.uint8).copy()).cuda() if len(scene.triangles) else None
         gpu_ctx.build_device(d_sph.data_ptr() if d_sph is not None else None, len(scene.spheres),
                              d_tri.data_ptr() if d_tri is not None else None, len(scene.triangles), scene.materials)
         got_fs = gpu_ctx.flat_scene()
-        got = _flat_bytes(got_fs.c)
+        got = _flat_bytes(got_fs.c, wide=True)
         for k in want:
             assert got[k] == want[k], f"{name}: {k} differ"
         assert (got_fs.c.n_nodes, got_fs.c.max_depth, got_fs.c.n_nodes4, got_fs.c.max_stack4) == want_counts, name
