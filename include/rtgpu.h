@@ -262,6 +262,30 @@ int  rtgpu_render_device(rtgpu_ctx *ctx, const rtgpu_camera *cam, const rtgpu_se
                          void *d_accum_rgba, void *d_prim_id, void *stream,
                          rtgpu_stats *stats);
 
+/* The entry point that ALLOCATES NOTHING.  It has no counterpart in the reference (nor has
+ * anything else here); it exists for callers that cannot call hipMalloc: code
+ * under HIP graph capture, tight serving / frame loops, harnesses that forbid allocation.
+ * Same frame as rtgpu_render_device, bit for bit (same kernels); what differs is where the
+ * launch keeps its scratch - the work-queue head, the counters and the chunk planes live in a
+ * static device array of the library (one copy per GPU, held until the process ends) instead
+ * of context buffers that grow on demand.  No hipMalloc, hipFree or other allocating routine
+ * is reached from this call; it is asynchronous on `stream` like rtgpu_render_device.
+ * Limits, each answered with a non-zero return and a message instead of an allocation:
+ *   - chunk planes: ceil(spp / chunk_samples) x output pixels x 16 B must fit
+ *     rtgpu_static_scratch_bytes() (64 MiB: 1920x1080 in up to 2 chunks, 1280x720 in up to 4;
+ *     one chunk - chunk_samples >= spp - needs no planes and fits any frame);
+ *   - the traversal stack of the uploaded tree must fit LDS (true for every tree up to depth
+ *     30, or 36 four-wide stack entries; deeper trees need the overflow stack of
+ *     rtgpu_render_device);
+ *   - no RTGPU_FLAG_PROFILE; counters of RTGPU_FLAG_STATS are read with rtgpu_profile_counters.
+ * All contexts of a process on one GPU share that GPU's array and it keeps the last call's
+ * contents (the call clears what has to start at zero): two calls that OVERLAP on one GPU -
+ * two contexts, or one context from two threads - race.  Calls of one context on different
+ * streams are ordered by the library as for rtgpu_render_device. */
+int  rtgpu_render_device_static(rtgpu_ctx *ctx, const rtgpu_camera *cam, const rtgpu_settings *s,
+                                void *d_accum_rgba, void *d_prim_id, void *stream);
+uint64_t rtgpu_static_scratch_bytes(void);
+
 /* Duration of the trace kernel of the last render call on this context,
  * measured with HIP events on the stream the kernel ran on.  Synchronises. */
 int  rtgpu_last_kernel_ms(rtgpu_ctx *ctx, float *ms);

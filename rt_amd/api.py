@@ -144,6 +144,8 @@ lib.rtgpu_render_poll.argtypes = [C.c_void_p, _P(C.c_int)]
 lib.rtgpu_render_end.argtypes = [C.c_void_p, _P(Stats)]
 lib.rtgpu_render_device.argtypes = [
     C.c_void_p, _P(Camera), _P(Settings), C.c_void_p, C.c_void_p, C.c_void_p, _P(Stats)]
+lib.rtgpu_render_device_static.argtypes = [C.c_void_p, _P(Camera), _P(Settings), C.c_void_p, C.c_void_p, C.c_void_p]
+lib.rtgpu_static_scratch_bytes.restype = C.c_uint64
 lib.rtgpu_profile_counters.argtypes = [C.c_void_p, _P(C.c_uint64)]
 lib.rtgpu_last_kernel_ms.argtypes = [C.c_void_p, _P(C.c_float)]
 lib.rtgpu_last_kernel_name.argtypes = [C.c_void_p]
@@ -442,6 +444,12 @@ class Context:
         self._check(lib.rtgpu_render_device(
             self._h, C.byref(cam), C.byref(settings), accum_ptr, ids_ptr, stream,
             C.byref(stats) if stats is not None else None))
+
+    def render_device_static(self, cam, settings, accum_ptr, ids_ptr=None, stream=None):
+        """rtgpu_render_device_static: the same frame with the launch's scratch in the library's
+        static device array - the entry point that allocates nothing."""
+        self._check(lib.rtgpu_render_device_static(
+            self._h, C.byref(cam), C.byref(settings), accum_ptr, ids_ptr, stream))
 
     def profile_counters(self):
         out = (C.c_uint64 * 32)()

@@ -1021,6 +1021,38 @@ __global__ __launch_bounds__(256) void untile_kernel(const T *gathered, T *image
   }
 }
 
+// ---- static device scratch of rtgpu_render_device_static (the entry point that allocates
+// nothing, include/rtgpu.h) ---------------------------------------------------------------
+// One array per GPU the library runs on, held until the process ends:
+//   [0, kStaticHeader)                 queue head + counters of the launch (the 256 B the
+//                                      context's d_counters holds for the other entry points)
+//   [kStaticHeader, kStaticScratch)    chunk planes: n_chunks x output pixels x 16 B
+// In HOST code `g_static_scratch` is only a stand-in for the symbol, not a device address: the
+// address comes from hipGetSymbolAddress, once per device with that device current
+// (static_scratch_for, called by rtgpu_create), and that pointer is what kernels, memsets and
+// copies get.
+constexpr size_t kStaticHeader = 4096;
+constexpr size_t kStaticPlanes = 64ull << 20;  // 1920x1080 in up to 2 chunks, 1280x720 in up to 4
+constexpr size_t kStaticScratch = kStaticHeader + kStaticPlanes;
+static __device__ __align__(256) unsigned char g_static_scratch[kStaticScratch];
+constexpr int kMaxDevices = 64;
+unsigned char *g_static_ptr[kMaxDevices] = {};  // per device: where ITS copy of the array lives
+
+// The current device must be `device`.  NULL + message on failure.
+unsigned char *static_scratch_for(int device, std::string &err) {
+  if (device < 0 || device >= kMaxDevices) { err = "static scratch: device index beyond the table"; return nullptr; }
+  if (!g_static_ptr[device]) {
+    void *p = nullptr;
+    hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_static_scratch));
+    if (e != hipSuccess || !p) {
+      err = std::string("hipGetSymbolAddress(static scratch): ") + hipGetErrorString(e);
+      return nullptr;
+    }
+    g_static_ptr[device] = (unsigned char *)p;
+  }
+  return g_static_ptr[device];
+}
+
 }  // namespace
 
 // =============================== C ABI ===========================================
@@ -1047,6 +1079,7 @@ struct rtgpu_ctx {
   // names: ev_last marks the end of the last launch's work (trace + combine) and a launch on
   // ANOTHER stream waits for it first, so two frames never run on the scratch at once.
   unsigned long long *last_counters = nullptr;  // where the last launch kept its counters (own buffer or static scratch)
+  unsigned char *static_scratch = nullptr;  // this GPU's g_static_scratch (static_scratch_for)
   char kernel_name[48] = "";  // instantiation of the last launch, as rocprofv3 prints it
   hipEvent_t ev_last = nullptr;
   hipStream_t last_stream = nullptr;
@@ -1186,6 +1219,15 @@ extern "C" int rtgpu_create(rtgpu_ctx **out, int device_index) {
     rtgpu::set_global_error(std::string("rtgpu is built for gfx950 only, device is ") + prop.gcnArchName);
     rtgpu_destroy(ctx);
     return 2;
+  }
+  {
+    std::string serr;
+    ctx->static_scratch = static_scratch_for(device_index, serr);
+    if (!ctx->static_scratch) {
+      rtgpu::set_global_error("rtgpu_create: " + serr);
+      rtgpu_destroy(ctx);
+      return 2;
+    }
   }
   ctx->num_cus = prop.multiProcessorCount;
   ctx->variant = -1;  // by scene, unless RTGPU_REFILL names one
@@ -1534,6 +1576,20 @@ extern "C" int rtgpu_render_device(rtgpu_ctx *ctx, const rtgpu_camera *cam, cons
   if (!ctx) return 1;
   return launch_frame(ctx, cam, s, d_accum_rgba, d_prim_id, stream_, stats, LaunchScratch{ctx->d_counters, nullptr, 0, true});
 }
+
+// The entry point that allocates nothing (include/rtgpu.h): the launch's scratch - queue head,
+// counters, chunk planes - lives in this GPU's static array; no hipMalloc / hipFree or any
+// allocating routine is reached from here.
+extern "C" int rtgpu_render_device_static(rtgpu_ctx *ctx, const rtgpu_camera *cam, const rtgpu_settings *s,
+                                          void *d_accum_rgba, void *d_prim_id, void *stream_) {
+  if (!ctx) return 1;
+  if (!ctx->static_scratch) { ctx->err = "static scratch of this GPU was not resolved at rtgpu_create"; return 2; }
+  if (s && (s->flags & RTGPU_FLAG_PROFILE)) { ctx->err = "rtgpu_render_device_static: RTGPU_FLAG_PROFILE is not supported"; return 1; }
+  LaunchScratch sc{(unsigned long long *)ctx->static_scratch, (float4 *)(ctx->static_scratch + kStaticHeader), kStaticPlanes, false};
+  return launch_frame(ctx, cam, s, d_accum_rgba, d_prim_id, stream_, nullptr, sc);
+}
+
+extern "C" uint64_t rtgpu_static_scratch_bytes(void) { return (uint64_t)kStaticPlanes; }
 
 namespace {
 int launch_frame(rtgpu_ctx *ctx, const rtgpu_camera *cam, const rtgpu_settings *s, void *d_accum_rgba, void *d_prim_id,

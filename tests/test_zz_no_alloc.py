@@ -1,0 +1,83 @@
+"""rtgpu_render_device_static, the entry point that allocates nothing: its launch scratch
+(queue head, counters, chunk planes) is a static device array of the library.  Called through
+the C ABI and compared bit for bit with rtgpu_render_device on two calls in a row, the second
+with a smaller input (the array keeps the first call's contents), then against the oracle;
+free device memory must not move across the calls; sizes beyond the array are refused.
+(Named to be collected last: the round's end runs pytest -x.)"""
+import numpy as np
+import pytest
+
+from util import assert_bit_equal, make_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(ra, ctx, cam, st):
+    """The same frame through rtgpu_render_device and rtgpu_render_device_static."""
+    import torch
+    n = st.width * st.height
+    want = torch.zeros((n, 4), dtype=torch.float32, device="cuda")
+    want_ids = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    got = torch.full((n, 4), 7.0, dtype=torch.float32, device="cuda")      # stale output: must be overwritten
+    got_ids = torch.full((n,), 5, dtype=torch.int32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx.render_device(cam, st, want.data_ptr(), want_ids.data_ptr(), stream)
+    torch.cuda.synchronize()
+    want_counters = ctx.profile_counters()[1:7]
+    free_before = torch.cuda.mem_get_info()[0]
+    ctx.render_device_static(cam, st, got.data_ptr(), got_ids.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free_before, "device memory moved across the no-alloc call"
+    assert ctx.profile_counters()[1:7] == want_counters
+    assert torch.equal(got.view(torch.int32), want.view(torch.int32)), "radiance differs from rtgpu_render_device"
+    assert torch.equal(got_ids, want_ids)
+    return got, got_ids
+
+
+def test_static_scratch_entry_point(ra, oracle):
+    import torch
+    ctx = ra.Context(0)
+    try:
+        assert ra.lib.rtgpu_static_scratch_bytes() == 64 << 20
+        scene, cam = ra.Scene.builtin(0, aspect=16 / 9)
+        ctx.upload(scene)
+        # first call: 1280x720, 16 spp in 4 chunks = 59 MB of chunk planes, nearly the whole array
+        big = ra.default_settings(1280, 720, spp=16, max_depth=8, flags=ra.FLAG_STATS)
+        assert big.chunk_samples == 4
+        _pair(ra, ctx, cam, big)
+        # second call, smaller input, other chunking (3 chunks over 5 spp): stale planes must not leak
+        small = ra.default_settings(200, 120, spp=5, max_depth=8, chunk_samples=2, seed=3, flags=ra.FLAG_STATS)
+        cam_s = ra.look_at((13, 2, 3), (0, 0, 0), vfov=20.0, aspect=200 / 120)
+        got, got_ids = _pair(ra, ctx, cam_s, small)
+        st_o = small.copy()
+        st_o.flags = 0
+        b, ib, _ = oracle.render(ctx.flat_scene().c, cam_s, st_o, threads=8)
+        assert_bit_equal(got.cpu().numpy().reshape(120, 200, 4), b, "no-alloc frame vs oracle")
+        assert np.array_equal(got_ids.cpu().numpy().view(np.uint32).reshape(120, 200), ib)
+        # one chunk needs no planes at all: a frame of any size
+        one = ra.default_settings(1920, 1080, spp=2, max_depth=8, chunk_samples=2)
+        _pair(ra, ctx, ra.look_at((13, 2, 3), (0, 0, 0), vfov=20.0, aspect=16 / 9), one)
+        # a large tree through the four-wide nodes (kernel mode 6), two chunks
+        mesh, cam_m = ra.Scene.builtin(1, param=6, aspect=16 / 9)
+        ctx.upload(mesh)
+        _pair(ra, ctx, cam_m, ra.default_settings(640, 360, spp=4, max_depth=8, flags=ra.FLAG_STATS))
+        # beyond the array: refused with a message, nothing allocated, nothing launched
+        too_big = ra.default_settings(1920, 1080, spp=16, max_depth=8)     # 4 chunks x 33 MB
+        acc = torch.zeros((1920 * 1080, 4), dtype=torch.float32, device="cuda")
+        with pytest.raises(ra.RtgpuError, match="static scratch"):
+            ctx.render_device_static(cam, too_big, acc.data_ptr())
+        profile = ra.default_settings(64, 64, spp=1, max_depth=2, flags=ra.FLAG_PROFILE)
+        with pytest.raises(ra.RtgpuError, match="PROFILE"):
+            ctx.render_device_static(cam, profile, acc.data_ptr())
+        # a deep tree whose stack still fits LDS; one that does not is refused (no overflow stack here)
+        sph = [(float(3.0 ** i), 0.0, 0.0, float(0.25 * 3.0 ** i), 0) for i in range(-16, 40)]
+        ctx.upload(make_scene(ra, spheres=sph, materials=[(0, .5, .5, .5, 0)]))
+        st = ra.default_settings(32, 32, spp=2, max_depth=4)
+        cam_d = ra.look_at((-1e-9, 0.0, 0.0), (1, 0, 0), vfov=30.0, aspect=1.0)
+        if ctx.flat_scene().c.max_depth + 2 <= 32:
+            _pair(ra, ctx, cam_d, st)
+        else:
+            with pytest.raises(ra.RtgpuError, match="too deep"):
+                ctx.render_device_static(cam_d, st, acc.data_ptr())
+    finally:
+        ctx.close()
