@@ -1,22 +1,32 @@
 #!/usr/bin/env python3
 """bench.py — the headline metric of BASELINE.json on MI355X.
 
-A "step" is one pass of the trace loop over one frame of the default scene S0
-(SURVEY.md §8d).  At N=1 the workload is BASELINE.json configs[1] ("C2"):
-S0, 1920x1080, 16 spp, depth 8, one MI355X.  At N>1 the frame is split into
-16x16 tiles interleaved over the ranks (one process per GPU), every rank traces
-its tiles from a replicated scene, RCCL gathers the compact tile buffers to
-rank 0 and rank 0 de-interleaves them; the per-GPU work is held fixed (weak
-scaling) by tracing 16*N spp, so a step at N GPUs is a 16N-spp frame.
+A "step" is one pass of the trace loop over one frame.
 
-Prints ONE JSON line (rank 0).  `value` = rays (segments: primary + every
-bounce, counted by the kernel) traced by all ranks per second of wall time,
-inputs resident in HBM.  `roofline` is the trace kernel's algorithmic bytes
-(64 B/node + 48 B/triangle test + 16 B/sphere test + 32 B/
-material fetch + 16 B/pixel written, counted by the instrumented kernel on the
-same frame and checked against the oracle in tests) divided by the kernel's
-mean duration (HIP events on the stream it ran on) vs 8 TB/s HBM.
-`cpu_baseline` is the CPU oracle (oracle/rt_oracle.c) on a bounded sample.
+  --config c2 (default at N=1)  BASELINE.json configs[1]: S0, 1920x1080, 16 spp, depth 8 on one
+                                MI355X.  With N>1 ranks the per-GPU work is held fixed (16*N spp
+                                per frame): weak scaling.
+  --config c4 (default at N>1)  BASELINE.json configs[3]: S0, 3840x2160, 256 spp in total, depth 8,
+                                the frame split into 16x16 tiles interleaved over the N ranks:
+                                strong scaling.  (At N=1 it is the same frame on one GPU.)
+
+One process per GPU; every rank traces its tiles from a replicated scene into a compact tile
+buffer, RCCL gathers the buffers to rank 0 (each peer straight to the root) and rank 0
+de-interleaves them.  The gather of frame k overlaps the trace of frame k+1 (two compact
+buffers; the collective runs on RCCL's stream).
+
+Prints ONE JSON line (rank 0).  `value` = rays (segments: primary + every bounce, counted by the
+kernel) traced by all ranks per second of wall time, inputs and outputs resident in HBM.
+
+`roofline` names the bound SURVEY.md §8d gives the workload - FP32 VALU for S0, whose 29 KB
+tree is served from LDS - as counted flops / kernel time against the 157.3 TFLOP/s vector peak;
+`roofline.valu_issue` is the wave-instruction rate against the issue ceiling (nominal: one
+wave64 VALU instruction per SIMD per 2 cycles at 2.4 GHz; measured: tools/ubench/valu_issue.hip,
+profiles/r02/ubench_valu_issue.txt), `roofline.hbm` the memory side (measured traffic from the
+committed PMC passes of the same workload; algorithmic bytes for information).  At N=1 the
+`also` array carries C3 (S1, 1.31 M triangles, 1080p, 64 spp: HBM/L2-bound by §8d) and C4's frame
+on one GPU, measured outside the timed region.  `cpu_baseline` is the CPU oracle
+(oracle/rt_oracle.c) on a bounded sample.
 """
 import argparse
 import json
@@ -27,14 +37,14 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak (spec)
-VALU_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 vector (spec)
-VALU_ISSUE_PEAK_GINST = 614.4  # 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak (spec)
+VALU_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: peak FP32 vector = 1024 SIMDs x 2.4 GHz x 32 lanes x 2 flop
+VALU_ISSUE_PEAK_GINST = 1228.8  # the same peak in wave64 instructions: 1024 SIMDs x 2.4 GHz / 2 cycles (SIMD-32)
 
 
-def algorithmic_bytes(st, n_pixels, node_bytes=64):
-    """node_bytes: 64 (the C2 tree, read from its LDS copy) or 48 (packed nodes of trees of
-    1366 nodes or more, include/rtgpu_format.h)."""
+def algorithmic_bytes(st, n_pixels, node_bytes):
+    """SURVEY.md §8d.  node_bytes: 64 (BVH2 nodes; the C2 tree, read from its LDS copy), 48
+    (packed BVH2 nodes) or 96 (four-wide nodes) - what one node step of the launched mode reads."""
     return node_bytes * st["nodes"] + 48 * st["tri_tests"] + 16 * st["sphere_tests"] + 32 * st["scatters"] + 16 * n_pixels
 
 
@@ -42,23 +52,65 @@ def algorithmic_flops(st):
     return 34 * st["nodes"] + 47 * st["tri_tests"] + 21 * st["sphere_tests"] + 60 * st["scatters"]
 
 
-def measured_traffic(width, height, spp, depth, world):
-    """HBM bytes per launch of the trace kernel from the PMC passes of THIS
-    workload (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in runs of their own,
-    tools/final_measure.sh; units and gfx950 correction as MI355X_MICROARCH.md
-    prescribes, calibrated on the path's own access pattern with
-    tools/ubench/fetch_calib.hip).  Counters cannot be read from inside this
-    process, so the committed summary of the last profile is reported, and only
-    when it was taken on the same workload; otherwise null."""
-    path = os.path.join(ROOT, "profiles", "traffic.json")
+def committed_pmc(name, width, height, spp, depth):
+    """PMC figures of THIS workload from the committed summary of the last profile
+    (profiles/traffic.json, written by tools/update_profiles.py from rocprofv3 --pmc passes:
+    FETCH_SIZE / WRITE_SIZE in runs of their own, KiB -> B, gfx950 correction calibrated with
+    tools/ubench/fetch_calib.hip as MI355X_MICROARCH.md prescribes).  Counters cannot be read
+    from inside this process; None when the summary is of another workload."""
     try:
-        doc = json.load(open(path))
+        doc = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
     except (OSError, ValueError):
-        return None, None, None
-    wl = doc.get("workload", {})
-    if world != 1 or [wl.get(k) for k in ("width", "height", "spp", "depth")] != [width, height, spp, depth]:
-        return None, None, None
-    return int(doc["traffic_bytes_per_launch"]), doc.get("source"), doc
+        return None, {}
+    wl = doc.get("workloads", {}).get(name)
+    if not wl or [wl.get(k) for k in ("width", "height", "spp", "depth")] != [width, height, spp, depth]:
+        return None, doc.get("ubench", {})
+    return wl, doc.get("ubench", {})
+
+
+def node_bytes_of(ctx):
+    c = ctx.flat_scene().c
+    return 96 if c.nodes4 else 48 if c.nodes48 else 64
+
+
+def roofline_block(bound, counts, n_px, node_bytes, k_ms, kernel, pmc, ub):
+    """The roofline object of one launch: `bound` as SURVEY.md §8d names it for the workload."""
+    sec = k_ms * 1e-3
+    abytes = algorithmic_bytes(counts, n_px, node_bytes)
+    aflops = algorithmic_flops(counts)
+    traffic = int(pmc["traffic_bytes_per_launch"]) if pmc else None
+    valu = {"achieved_tflops": round(aflops / sec / 1e12, 3), "peak_tflops": VALU_PEAK_TFLOPS,
+            "frac": round(aflops / sec / 1e12 / VALU_PEAK_TFLOPS, 4), "flops_per_ray": round(aflops / counts["rays"], 1)}
+    hbm = {"measured_gbs": round(traffic / sec / 1e9, 1) if traffic else None, "peak_gbs": HBM_PEAK_GBS,
+           "frac": round(traffic / sec / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+           "achievable_peak_gbs": ub.get("hbm_read_gbs"),
+           "algorithmic_gbs": round(abytes / sec / 1e9, 1), "algorithmic_bytes_per_launch": int(abytes),
+           "bytes_per_ray": round(abytes / counts["rays"], 1),
+           "note": "measured = FETCH_SIZE + WRITE_SIZE of the committed PMC passes of this workload / this run's kernel "
+                   "time; algorithmic = every node / primitive / material fetch a ray makes, most of them served by "
+                   "LDS, L1 and L2 - informational, never a fraction of HBM"}
+    out = {"bound": bound, "traffic": traffic, "traffic_source": pmc.get("source") if pmc else None,
+           "kernel": kernel, "kernel_ms": round(k_ms, 4),
+           "kernel_mrays_per_s": round(counts["rays"] / sec / 1e6, 1), "valu": valu, "hbm": hbm}
+    if bound == "valu":
+        out.update({"achieved": valu["achieved_tflops"], "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": valu["frac"]})
+    else:
+        out.update({"achieved": hbm["measured_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm["frac"]})
+    if pmc and "valu_insts_per_launch" in pmc:
+        rate = pmc["valu_insts_per_launch"] / sec / 1e9
+        out["valu_issue"] = {
+            "achieved_ginst_per_s": round(rate, 1), "peak_ginst_per_s": VALU_ISSUE_PEAK_GINST,
+            "frac": round(rate / VALU_ISSUE_PEAK_GINST, 3),
+            "measured_peak_ginst_per_s": ub.get("valu_issue_peak_ginst_per_s"),
+            "frac_of_measured_peak": round(rate / ub["valu_issue_peak_ginst_per_s"], 3) if ub.get("valu_issue_peak_ginst_per_s") else None,
+            "lane_utilisation": pmc.get("valu_lane_utilisation"),
+            "insts_per_ray": round(pmc["valu_insts_per_launch"] * 64 / counts["rays"], 1),
+            "note": "wave64 VALU instructions per launch from the committed PMC pass (SQ_INSTS_VALU) / this run's kernel "
+                    "time.  peak: 1024 SIMDs x 2.4 GHz / 2 cycles; measured_peak: the best sustained rate of an independent "
+                    "v_fma_f32 stream on all CUs (the chip lowers its clock under that load), " + str(ub.get("source"))}
+    else:
+        out["valu_issue"] = None
+    return out
 
 
 def cpu_baseline(width, height, depth, sample_spp):
@@ -89,16 +141,48 @@ def cpu_baseline(width, height, depth, sample_spp):
     }
 
 
+def also_workload(ra, torch, ctx, dev, name, label, kind, param, w, h, spp, depth, bound, reps):
+    """One more workload on this GPU, outside the timed region: `reps` frames after one
+    instrumented frame (counts) that doubles as the warm-up."""
+    scene, cam = ra.Scene.builtin(kind, param=param, aspect=w / h)
+    ctx.upload(scene)
+    acc = torch.zeros((h * w, 4), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    st = ra.default_settings(w, h, spp=spp, max_depth=depth)
+    st_s = st.copy()
+    st_s.flags |= ra.FLAG_STATS
+    stats = ra.Stats()
+    ctx.render_device(cam, st_s, acc.data_ptr(), None, stream, stats)
+    counts = stats.as_dict()
+    ms, t0 = [], time.perf_counter()
+    for _ in range(reps):
+        ctx.render_device(cam, st, acc.data_ptr(), None, stream)
+        ms.append(ctx.kernel_ms())
+    torch.cuda.synchronize(dev)
+    wall_ms = (time.perf_counter() - t0) * 1e3 / reps
+    k_ms = sum(ms) / len(ms)
+    pmc, ub = committed_pmc(name, w, h, spp, depth)
+    del acc
+    return {"workload": label + f" ({scene.n_prims} prims), {w}x{h}, {spp} spp, depth {depth}, one GPU",
+            "ms": round(wall_ms, 3), "frames": reps, "rays_per_frame": counts["rays"],
+            "mrays_per_s": round(counts["rays"] / (wall_ms * 1e-3) / 1e6, 1),
+            "roofline": roofline_block(bound, counts, w * h, node_bytes_of(ctx), k_ms, ctx.kernel_name(), pmc, ub)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--spp", type=int, default=16, help="samples per pixel PER GPU (weak scaling)")
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", choices=("c2", "c4"), default=None,
+                    help="c2: 1080p, 16 spp per GPU (weak scaling over N); c4: 4K, 256 spp in total (strong scaling); "
+                         "default c2 at --gpus 1, c4 otherwise")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--spp", type=int, default=None, help="c2: samples per pixel PER GPU; c4: per frame")
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--cpu-spp", type=int, default=16, help="spp of the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--no-also", action="store_true", help="skip the C3 / C4-frame measurements of the `also` array")
     args = ap.parse_args()
 
     import torch
@@ -128,8 +212,20 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    W, H, depth = args.width, args.height, args.depth
-    spp = args.spp * world
+    config = args.config or ("c2" if world == 1 else "c4")
+    depth = args.depth
+    if config == "c2":
+        W, H = args.width or 1920, args.height or 1080
+        spp_arg = args.spp or 16
+        spp = spp_arg * world                      # per-GPU work fixed
+        scaling = "weak"
+        steps, warmup = args.steps or 20, 3 if args.warmup is None else args.warmup
+    else:
+        W, H = args.width or 3840, args.height or 2160
+        spp_arg = args.spp or 256
+        spp = spp_arg                              # the frame is fixed, the ranks split it
+        scaling = "strong"
+        steps, warmup = args.steps or 5, 1 if args.warmup is None else args.warmup
     # 16x16 tiles: the slowest of 8 ranks is then 0.8 % above the mean (64x64: 4.2 %, 32x32:
     # 1.3 %; tools/gpu_rank_balance.py), and every rank owns the same number of tiles.  The
     # image does not depend on the tile size.
@@ -143,53 +239,76 @@ def main():
     st = ra.default_settings(W, H, spp=spp, max_depth=depth, tile_size=tile, rank=rank,
                              world_size=world, flags=flags)
     n_out = ra.compact_pixels(W, H, tile, 0, world) if compact else W * H  # rank 0 has the most tiles
-    accum = torch.zeros((n_out, 4), dtype=torch.float32, device=dev)
-    image = torch.zeros((H * W, 4), dtype=torch.float32, device=dev) if compact else accum
-    gathered = (torch.zeros((world * n_out, 4), dtype=torch.float32, device=dev)
+    # two compact buffers: frame k+1 is traced while frame k is gathered
+    accum = [torch.zeros((n_out, 4), dtype=torch.float32, device=dev) for _ in range(2 if compact else 1)]
+    image = torch.zeros((H * W, 4), dtype=torch.float32, device=dev) if compact else accum[0]
+    gathered = ([torch.zeros((world * n_out, 4), dtype=torch.float32, device=dev) for _ in range(2)]
                 if compact and rank == 0 else None)
     stream = torch.cuda.current_stream(dev)
+    in_flight = [None, None]   # the gather of the frame last traced into accum[b]
 
-    def step():
-        ctx.render_device(cam, st, accum.data_ptr(), None, stream.cuda_stream)
-        ms = None
-        if compact:
-            # real exchange step of the path: tiles -> rank 0
-            if share_gpu:  # rehearsal only: gloo cannot move device tensors
-                host = accum.cpu()
-                parts = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
-                dist.gather(host, parts, dst=0)
-                if rank == 0:
-                    gathered.copy_(torch.cat(parts))
-            else:
-                dist.gather(accum, list(gathered.chunk(world)) if rank == 0 else None, dst=0)
+    def finish(b):
+        """Frame in buffer b: wait for its gather (stream-side, the host does not block) and de-interleave."""
+        w = in_flight[b]
+        if w is None:
+            return
+        in_flight[b] = None
+        if w is not True:
+            w.wait()
+        if rank == 0:
+            ctx.untile_device(gathered[b].data_ptr(), image.data_ptr(), W, H, tile, world, 16, stream.cuda_stream)
+
+    def step(k):
+        if not compact:
+            ctx.render_device(cam, st, accum[0].data_ptr(), None, stream.cuda_stream)
+            return ctx.kernel_ms()  # HIP events around the trace kernel on `stream`
+        b = k & 1
+        finish(b)                  # frame k-2 (same buffer): nothing left to do unless it was skipped
+        ctx.render_device(cam, st, accum[b].data_ptr(), None, stream.cuda_stream)
+        # the exchange step of the path (SURVEY.md §8e): compact tiles -> rank 0
+        if share_gpu:  # rehearsal only: gloo cannot move device tensors
+            host = accum[b].cpu()
+            parts = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
+            dist.gather(host, parts, dst=0)
             if rank == 0:
-                ctx.untile_device(gathered.data_ptr(), image.data_ptr(), W, H, tile, world, 16,
-                                  stream.cuda_stream)
-        ms = ctx.kernel_ms()  # HIP events around the trace kernel on `stream`
-        return ms
+                gathered[b].copy_(torch.cat(parts))
+            in_flight[b] = True
+        else:
+            in_flight[b] = dist.gather(accum[b], list(gathered[b].chunk(world)) if rank == 0 else None, dst=0,
+                                       async_op=True)
+        finish(b ^ 1)              # frame k-1: its gather ran beside this frame's trace
+        return None
+
+    def drain():
+        finish(0)
+        finish(1)
 
     # counts for the roofline: instrumented variant of the same frame, untimed
     st_stats = st.copy()
     st_stats.flags = flags | ra.FLAG_STATS
     stats = ra.Stats()
-    ctx.render_device(cam, st_stats, accum.data_ptr(), None, stream.cuda_stream, stats)
+    ctx.render_device(cam, st_stats, accum[0].data_ptr(), None, stream.cuda_stream, stats)
     counts = stats.as_dict()
 
-    for _ in range(args.warmup):
-        step()
+    for k in range(warmup):
+        step(k)
+    drain()
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     kernel_ms = []
-    for _ in range(args.steps):
-        kernel_ms.append(step())
+    for k in range(steps):
+        kernel_ms.append(step(k))
+    drain()
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
+    if compact:
+        kernel_ms = [ctx.kernel_ms()]  # the last frame's kernel (reading it every step would serialise the pipeline)
 
     t_all = torch.tensor([dt], dtype=torch.float64, device=dev)
     rays_all = torch.tensor([float(counts["rays"])], dtype=torch.float64, device=dev)
@@ -204,60 +323,35 @@ def main():
     if rank == 0:
         k_ms = sum(kernel_ms) / len(kernel_ms)
         n_px_rank = counts["paths"] // spp
-        abytes = algorithmic_bytes(counts, n_px_rank, (96 if ctx.flat_scene().c.nodes4 else 48 if ctx.flat_scene().c.nodes48 else 64))
-        aflops = algorithmic_flops(counts)
-        achieved = abytes / (k_ms * 1e-3) / 1e9
-        traffic, traffic_src, pmc = measured_traffic(W, H, args.spp, depth, world)
+        pmc, ub = committed_pmc(config, W, H, spp_arg, depth) if world == 1 else (None, committed_pmc("", 0, 0, 0, 0)[1])
+        ms_step = dt / steps * 1e3
+        name = "C2" if config == "c2" else "C4"
         out = {
-            "metric": "Mrays/s (whole job)", "value": round(rays_per_step * args.steps / dt / 1e6, 2),
-            "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "metric": "Mrays/s (whole job)", "value": round(rays_per_step * steps / dt / 1e6, 2),
+            "unit": "Mrays/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": round(ms_step, 4), "higher_is_better": True,
+            "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": f"C2: procedural scene S0 (RTIOW cover, {scene.n_prims} prims), "
-                            f"{W}x{H}, {args.spp} spp per GPU ({spp} spp total), depth {depth}, "
-                            f"pinhole, {tile}x{tile} tiles interleaved over {world} GPU(s)"
-                            + (", RCCL gather to rank 0" if compact and not share_gpu else "")
+                "workload": f"{name}: procedural scene S0 (RTIOW cover, {scene.n_prims} prims), {W}x{H}, "
+                            + (f"{spp_arg} spp per GPU ({spp} spp total)" if config == "c2" else f"{spp} spp per frame (split over the ranks)")
+                            + f", depth {depth}, pinhole, {tile}x{tile} tiles interleaved over {world} GPU(s)"
+                            + (", RCCL gather to rank 0 overlapped with the next frame's trace" if compact and not share_gpu else "")
                             + (" [REHEARSAL: all ranks on one GPU, gloo gather via host]" if share_gpu else ""),
                 "rays_per_step": int(rays_per_step), "paths_per_step": W * H * spp,
-                "mrays_per_s_per_gpu": round(rays_per_step * args.steps / dt / 1e6 / world, 2),
-                "ms_per_frame_1080p_16spp": round(dt / args.steps * 1e3, 4) if world == 1 else None,
+                "mrays_per_s_per_gpu": round(rays_per_step * steps / dt / 1e6 / world, 2),
+                "ms_per_frame_1080p_16spp": round(ms_step, 4) if (world == 1 and config == "c2" and (W, H, spp) == (1920, 1080, 16)) else None,
             },
-            "roofline": {
-                "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "traffic_source": traffic_src,
-                "note": "achieved counts ALGORITHMIC bytes (every node/primitive/material fetch a ray makes); "
-                        "most are served from the LDS node cache and the vector L1, so frac can exceed what "
-                        "HBM delivers - `traffic` is what actually crossed the L2's memory side; the kernel "
-                        "is bound by VALU issue and divergent-fetch latency, see `valu` and DESIGN.md",
-                "kernel": "trace_kernel<STATS=0,REFILL=16>", "kernel_ms": round(k_ms, 4),
-                "algorithmic_bytes_per_launch": int(abytes),
-                "bytes_per_ray": round(abytes / counts["rays"], 1),
-                "valu": {"achieved_tflops": round(aflops / (k_ms * 1e-3) / 1e12, 3),
-                         "peak_tflops": VALU_PEAK_TFLOPS,
-                         "frac": round(aflops / (k_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4),
-                         "flops_per_ray": round(aflops / counts["rays"], 1)},
-                "kernel_mrays_per_s": round(counts["rays"] / (k_ms * 1e-3) / 1e6, 1),
-                # the bound that actually holds on this workload: VALU issue slots.  A wave64 VALU
-                # instruction occupies its SIMD for 4 cycles: 1024 SIMDs x 2.4 GHz / 4 = 614.4 G
-                # wave-instructions/s.  Instruction count from the committed PMC pass of this workload.
-                "valu_issue": None if not pmc or "valu_insts_per_launch" not in pmc else {
-                    "achieved_ginst_per_s": round(pmc["valu_insts_per_launch"] / (k_ms * 1e-3) / 1e9, 1),
-                    "peak_ginst_per_s": VALU_ISSUE_PEAK_GINST,
-                    "frac": round(pmc["valu_insts_per_launch"] / (k_ms * 1e-3) / 1e9 / VALU_ISSUE_PEAK_GINST, 3),
-                    "lane_utilisation": pmc.get("valu_lane_utilisation"),
-                    "insts_per_ray": round(pmc["valu_insts_per_launch"] * 64 / counts["rays"], 1),
-                    "note": "instruction count from the committed PMC pass, kernel time from this run, "
-                            "peak at the nominal 2.4 GHz (one wave64 VALU instruction per SIMD per 4 cycles): "
-                            "0.99-1.03 across runs and counter sources, i.e. every VALU issue slot of the "
-                            "launch is used"},
-            },
+            "roofline": roofline_block("valu", counts, n_px_rank, node_bytes_of(ctx), k_ms, ctx.kernel_name(), pmc, ub),
         }
         if args.cpu_spp > 0 and world == 1:
-            out["cpu_baseline"] = cpu_baseline(W, H, depth, args.cpu_spp)
+            out["cpu_baseline"] = cpu_baseline(1920, 1080, depth, args.cpu_spp)
         else:
             out["cpu_baseline"] = None
+        if world == 1 and not args.no_also:
+            also = [also_workload(ra, torch, ctx, dev, "c3", "C3: procedural mesh S1 level 8", 1, 8, 1920, 1080, 64, 8, "hbm", 3)]
+            if config == "c2":
+                also.append(also_workload(ra, torch, ctx, dev, "c4", "C4's frame: S0", 0, 0, 3840, 2160, 256, 8, "valu", 2))
+            out["also"] = also
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
