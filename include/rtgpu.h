@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define RTGPU_ABI_VERSION 4u
+#define RTGPU_ABI_VERSION 5u
 
 /* ---- scene description (host side, caller-owned) ------------------------ */
 
@@ -233,6 +233,25 @@ void rtgpu_flat_scene_free(rtgpu_flat_scene *fs);
 int  rtgpu_render(rtgpu_ctx *ctx, const rtgpu_camera *cam, const rtgpu_settings *s,
                   float *accum_rgba, uint32_t *prim_id, rtgpu_stats *stats);
 
+/* The progressive frame loop of an interactive front-end (the reference's loop,
+ * code/first.cpp:78-88, presents one image per iteration): trace `spp` more samples and get
+ * the RESOLVED frame back.  The float accumulation never leaves the GPU - it lives in the
+ * context between calls, owned by it like every device buffer (arena rule of
+ * code/base/memory.cxx:23-34: allocated once, kept) - and only 4 bytes per pixel cross PCIe,
+ * through a pinned staging buffer with an asynchronous copy.  With RTGPU_FLAG_ACCUMULATE the
+ * frame adds to the resident sum (give each call the next sample_offset); without it, after a
+ * size change, after rtgpu_resident_reset and after a scene upload, build or refit the sum
+ * starts again from this frame.  rgba8: host, width*height 0xRRGGBBAA, row 0 = bottom; may be
+ * NULL, then read the frame in place from rtgpu_resolved_frame() (context-owned pinned host
+ * memory, valid until the next call on the context).  Whole frames only (no
+ * RTGPU_FLAG_COMPACT).  Blocking.  rtgpu_resident_accum copies the float sums out when a
+ * caller wants them (rtgpu_render's accum_rgba layout). */
+int  rtgpu_render_resolved(rtgpu_ctx *ctx, const rtgpu_camera *cam, const rtgpu_settings *s,
+                           uint32_t *rgba8 /* may be NULL */, rtgpu_stats *stats /* may be NULL */);
+const uint32_t *rtgpu_resolved_frame(const rtgpu_ctx *ctx);
+int  rtgpu_resident_accum(rtgpu_ctx *ctx, float *accum_rgba, uint64_t n_pixels);
+void rtgpu_resident_reset(rtgpu_ctx *ctx);
+
 /* Non-blocking form of rtgpu_render, for a frame loop that must keep running
  * while the frame is traced (the reference's loop pumps window messages every
  * iteration, code/first.cpp:78-88, and its author wants tracing to go on while
@@ -322,12 +341,57 @@ int  rtgpu_untile_device(rtgpu_ctx *ctx, const void *d_gathered, void *d_image,
                          uint32_t width, uint32_t height, uint32_t tile_size,
                          uint32_t world_size, uint32_t elem_bytes, void *stream);
 
+/* ---- several GPUs of one node behind one handle ------------------------------
+ * No reference counterpart (the reference is one process, one thread, one GPU for display:
+ * code/gfx/gfx.cpp:36).  One process, one context and one worker thread per GPU, one RCCL
+ * communicator (ncclCommInitAll).  The scene is flattened once on the host and replicated;
+ * a frame is cut into tile_size x tile_size tiles, tile t belongs to GPU t mod N; every GPU
+ * traces its tiles into a compact buffer; ONE exchange step - ncclGroupStart, N-1 ncclRecv on
+ * the root (GPU 0 of the list) and one ncclSend per peer, each peer straight to the root over
+ * its own xGMI link - then the root de-interleaves (untile kernel) and resolves.  Frames are
+ * pipelined two deep: _begin queues a frame on every GPU and returns, _end waits for the
+ * OLDEST queued frame and copies it out, so the exchange of frame k runs beside the trace of
+ * frame k+1 when the caller begins k+1 before ending k.  The image is bit-identical to the
+ * one-GPU frame for any N and tile size (the RNG is keyed on the global pixel).
+ * The worker threads never call back into the caller and touch nothing but HIP / RCCL: the
+ * single-threaded D3D11 device of the reference (code/gfx/gfx.cpp:36) stays with the thread
+ * that calls these functions, and all calls on a group come from that one thread.
+ * A device may appear more than once in `devices` (rehearsal of N ranks on a one-GPU box):
+ * RCCL does not accept that, and the exchange is then done with peer-to-peer copies. */
+typedef struct rtgpu_group rtgpu_group;
+int  rtgpu_group_create(rtgpu_group **out, const int *devices, int n_devices);
+void rtgpu_group_destroy(rtgpu_group *g);
+const char *rtgpu_group_last_error(const rtgpu_group *g);   /* g may be NULL: last create error */
+int  rtgpu_group_size(const rtgpu_group *g);
+/* builder: 0 = binned SAH on the host (built once, uploaded to every GPU), 1 = LBVH, built by
+ * every GPU for itself from the uploaded primitives (same bytes on every GPU). */
+int  rtgpu_group_upload_scene(rtgpu_group *g, const rtgpu_scene_desc *scene, int builder);
+/* settings: rank, world_size and RTGPU_FLAG_COMPACT are set by the group; tile_size is used
+ * as given.  RTGPU_FLAG_ACCUMULATE adds to the frame the group holds from the previous call
+ * of the same size (resident per-GPU tile sums, as rtgpu_render_resolved). */
+int  rtgpu_group_render_begin(rtgpu_group *g, const rtgpu_camera *cam, const rtgpu_settings *s);
+/* Outputs of the oldest frame begun: accum_rgba (width*height float4, host) and rgba8
+ * (width*height 0xRRGGBBAA, host), either may be NULL; stats summed over the GPUs. */
+int  rtgpu_group_render_end(rtgpu_group *g, float *accum_rgba, uint32_t *rgba8, rtgpu_stats *stats);
+/* _begin + _end */
+int  rtgpu_group_render(rtgpu_group *g, const rtgpu_camera *cam, const rtgpu_settings *s,
+                        float *accum_rgba, uint32_t *rgba8, rtgpu_stats *stats);
+/* Trace-kernel time of the last ended frame on GPU `index` of the list (ms). */
+int  rtgpu_group_kernel_ms(rtgpu_group *g, int index, float *ms);
+
 /* Camera helper: RTIOW look-at thin-lens camera, computed in f64 and rounded
  * once to f32 so all callers agree bit-for-bit.  Row-vector convention of
  * code/math/mat.cxx:12-20 is not involved: the camera is stored as vectors. */
 void rtgpu_camera_look_at(rtgpu_camera *cam, const float from[3], const float at[3],
                           const float up[3], float vfov_deg, float aspect,
                           float aperture, float focus_dist);
+
+/* The same camera from a camera-to-world rt::Mat4x4 (code/math/mat.hxx:2-4, 16 floats row
+ * by row) in the reference's ROW-VECTOR convention (code/math/mat.cxx:12-20: world = p * M):
+ * rows 0..2 = the camera's right, up and back axes in world space, row 3 = the eye (where
+ * translate2 puts a translation, mat.cxx:93-102).  The camera looks down its -z axis. */
+void rtgpu_camera_from_matrix(rtgpu_camera *cam, const float m[16], float vfov_deg, float aspect,
+                              float aperture, float focus_dist);
 
 void rtgpu_default_settings(rtgpu_settings *s, uint32_t width, uint32_t height,
                             uint32_t spp, uint32_t max_depth);

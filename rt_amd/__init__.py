@@ -20,6 +20,8 @@ from .api import (  # noqa: F401
     look_at,
     write_png,
     write_ppm,
+    Group,
+    camera_from_matrix,
     MATERIAL_DTYPE,
     SPHERE_DTYPE,
     TRIANGLE_DTYPE,

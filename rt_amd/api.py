@@ -146,6 +146,23 @@ lib.rtgpu_render_device.argtypes = [
     C.c_void_p, _P(Camera), _P(Settings), C.c_void_p, C.c_void_p, C.c_void_p, _P(Stats)]
 lib.rtgpu_render_device_static.argtypes = [C.c_void_p, _P(Camera), _P(Settings), C.c_void_p, C.c_void_p, C.c_void_p]
 lib.rtgpu_static_scratch_bytes.restype = C.c_uint64
+lib.rtgpu_render_resolved.argtypes = [C.c_void_p, _P(Camera), _P(Settings), C.c_void_p, _P(Stats)]
+lib.rtgpu_resolved_frame.argtypes = [C.c_void_p]
+lib.rtgpu_resolved_frame.restype = C.c_void_p
+lib.rtgpu_resident_accum.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+lib.rtgpu_resident_reset.argtypes = [C.c_void_p]
+lib.rtgpu_resident_reset.restype = None
+lib.rtgpu_group_create.argtypes = [_P(C.c_void_p), _P(C.c_int), C.c_int]
+lib.rtgpu_group_destroy.argtypes = [C.c_void_p]
+lib.rtgpu_group_destroy.restype = None
+lib.rtgpu_group_last_error.argtypes = [C.c_void_p]
+lib.rtgpu_group_last_error.restype = C.c_char_p
+lib.rtgpu_group_size.argtypes = [C.c_void_p]
+lib.rtgpu_group_upload_scene.argtypes = [C.c_void_p, _P(SceneDesc), C.c_int]
+lib.rtgpu_group_render_begin.argtypes = [C.c_void_p, _P(Camera), _P(Settings)]
+lib.rtgpu_group_render_end.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, _P(Stats)]
+lib.rtgpu_group_render.argtypes = [C.c_void_p, _P(Camera), _P(Settings), C.c_void_p, C.c_void_p, _P(Stats)]
+lib.rtgpu_group_kernel_ms.argtypes = [C.c_void_p, C.c_int, _P(C.c_float)]
 lib.rtgpu_profile_counters.argtypes = [C.c_void_p, _P(C.c_uint64)]
 lib.rtgpu_last_kernel_ms.argtypes = [C.c_void_p, _P(C.c_float)]
 lib.rtgpu_last_kernel_name.argtypes = [C.c_void_p]
@@ -160,6 +177,8 @@ lib.rtgpu_untile_device.argtypes = [
 lib.rtgpu_camera_look_at.argtypes = [
     _P(Camera), C.c_float * 3, C.c_float * 3, C.c_float * 3, C.c_float, C.c_float, C.c_float, C.c_float]
 lib.rtgpu_camera_look_at.restype = None
+lib.rtgpu_camera_from_matrix.argtypes = [_P(Camera), C.c_float * 16, C.c_float, C.c_float, C.c_float, C.c_float]
+lib.rtgpu_camera_from_matrix.restype = None
 lib.rtgpu_default_settings.argtypes = [_P(Settings), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
 lib.rtgpu_default_settings.restype = None
 lib.rtgpu_scene_builtin.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, _P(SceneDesc), _P(Camera), C.c_float]
@@ -183,6 +202,15 @@ def look_at(frm, at, up=(0, 1, 0), vfov=20.0, aspect=16 / 9, aperture=0.0, focus
     cam = Camera()
     f3 = C.c_float * 3
     lib.rtgpu_camera_look_at(C.byref(cam), f3(*frm), f3(*at), f3(*up), vfov, aspect, aperture, focus_dist)
+    return cam
+
+
+def camera_from_matrix(m, vfov=20.0, aspect=16 / 9, aperture=0.0, focus_dist=10.0):
+    """m: 4x4 camera-to-world matrix, row-vector convention of the reference (rows = right, up,
+    back, eye)."""
+    cam = Camera()
+    flat = [float(x) for x in np.asarray(m, np.float32).reshape(16)]
+    lib.rtgpu_camera_from_matrix(C.byref(cam), (C.c_float * 16)(*flat), vfov, aspect, aperture, focus_dist)
     return cam
 
 
@@ -451,6 +479,23 @@ class Context:
         self._check(lib.rtgpu_render_device_static(
             self._h, C.byref(cam), C.byref(settings), accum_ptr, ids_ptr, stream))
 
+    def render_resolved(self, cam, settings, want_stats=False):
+        """rtgpu_render_resolved: the accumulation stays in the context, the resolved
+        0xRRGGBBAA frame [h, w] comes back.  Returns (rgba8, Stats or None)."""
+        out = np.zeros((settings.height, settings.width), np.uint32)
+        st = Stats() if want_stats else None
+        self._check(lib.rtgpu_render_resolved(self._h, C.byref(cam), C.byref(settings), out.ctypes.data,
+                                              C.byref(st) if want_stats else None))
+        return out, st
+
+    def resident_accum(self, width, height):
+        out = np.zeros((height, width, 4), np.float32)
+        self._check(lib.rtgpu_resident_accum(self._h, out.ctypes.data, width * height))
+        return out
+
+    def resident_reset(self):
+        lib.rtgpu_resident_reset(self._h)
+
     def profile_counters(self):
         out = (C.c_uint64 * 32)()
         self._check(lib.rtgpu_profile_counters(self._h, out))
@@ -479,3 +524,56 @@ class Context:
                       stream=None):
         self._check(lib.rtgpu_untile_device(
             self._h, gathered_ptr, image_ptr, width, height, tile_size, world, elem_bytes, stream))
+
+
+class Group:
+    """Several GPUs of one node behind one handle (rtgpu_group_*): one process, one worker
+    thread and one context per GPU, RCCL tile gather to the first device of the list."""
+
+    def __init__(self, devices):
+        self._h = C.c_void_p()
+        arr = (C.c_int * len(devices))(*devices)
+        if lib.rtgpu_group_create(C.byref(self._h), arr, len(devices)):
+            raise RtgpuError((lib.rtgpu_group_last_error(None) or b"").decode())
+        self.size = len(devices)
+
+    def _check(self, rc):
+        if rc:
+            raise RtgpuError((lib.rtgpu_group_last_error(self._h) or b"").decode())
+
+    def close(self):
+        if self._h:
+            lib.rtgpu_group_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, scene, builder="sah"):
+        self._check(lib.rtgpu_group_upload_scene(self._h, C.byref(scene.desc), {"sah": 0, "lbvh": 1}[builder]))
+
+    def render_begin(self, cam, settings):
+        self._check(lib.rtgpu_group_render_begin(self._h, C.byref(cam), C.byref(settings)))
+        self._shapes = getattr(self, "_shapes", []) + [(settings.height, settings.width)]  # only frames that began
+
+    def render_end(self, want_accum=True, want_rgba8=True):
+        shapes = getattr(self, "_shapes", [])
+        h, w = shapes.pop(0) if shapes else (0, 0)     # no frame begun: the library says so
+        acc = np.zeros((h, w, 4), np.float32) if want_accum else None
+        rgba = np.zeros((h, w), np.uint32) if want_rgba8 else None
+        st = Stats()
+        self._check(lib.rtgpu_group_render_end(self._h, acc.ctypes.data if want_accum else None,
+                                               rgba.ctypes.data if want_rgba8 else None, C.byref(st)))
+        return acc, rgba, st
+
+    def render(self, cam, settings, want_accum=True, want_rgba8=True):
+        self.render_begin(cam, settings)
+        return self.render_end(want_accum, want_rgba8)
+
+    def kernel_ms(self, index):
+        ms = C.c_float()
+        self._check(lib.rtgpu_group_kernel_ms(self._h, index, C.byref(ms)))
+        return float(ms.value)

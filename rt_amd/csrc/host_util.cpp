@@ -78,6 +78,22 @@ extern "C" void rtgpu_camera_look_at(rtgpu_camera *cam, const float from[3], con
   cam->lens_radius = aperture * 0.5f;
 }
 
+// The same camera from a camera-to-world matrix in the reference's convention
+// (code/math/mat.hxx:2-4 `f32 v[4][4]`; code/math/mat.cxx:12-20: ROW vectors, world = p * M,
+// so rows 0-2 are the camera's right / up / back axes in world space and row 3 - where
+// translate2 puts a translation, mat.cxx:93-102 - is the eye).  The camera looks down its -z
+// axis, y up (the y-up screen space of mat.cxx:104-129).  Axes need not be unit or exactly
+// orthogonal: the basis is rebuilt as rtgpu_camera_look_at does from eye, eye - back and up.
+extern "C" void rtgpu_camera_from_matrix(rtgpu_camera *cam, const float m[16], float vfov_deg, float aspect,
+                                         float aperture, float focus_dist) {
+  // (0,0,0,1) * M and (0,0,-1,1) * M, spelled as transformed_point spells them
+  const float eye[3] = {m[12], m[13], m[14]};
+  const float at[3] = {0.f * m[0] + 0.f * m[4] + -1.f * m[8] + 1.f * m[12], 0.f * m[1] + 0.f * m[5] + -1.f * m[9] + 1.f * m[13],
+                       0.f * m[2] + 0.f * m[6] + -1.f * m[10] + 1.f * m[14]};
+  const float up[3] = {m[4], m[5], m[6]};
+  rtgpu_camera_look_at(cam, eye, at, up, vfov_deg, aspect, aperture, focus_dist);
+}
+
 extern "C" void rtgpu_default_settings(rtgpu_settings *s, uint32_t width, uint32_t height,
                                        uint32_t spp, uint32_t max_depth) {
   std::memset(s, 0, sizeof(*s));

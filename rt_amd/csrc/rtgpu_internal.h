@@ -65,6 +65,12 @@ int  refit_device_ptrs(const void *d_spheres, uint32_t ns, const void *d_triangl
 int  check_prims_device(const void *d_spheres, uint32_t ns, const void *d_triangles, uint32_t nt, uint32_t n_materials,
                         uint32_t *d_flag, std::string &err, const char *who /* "refit" or "build": prefix of the message */);
 
+}  // namespace rtgpu
+// rtgpu_kernels.hip, for group.cpp: an already flattened scene of this process to one more GPU
+extern "C" int rtgpu_internal_upload_flat(rtgpu_ctx *ctx, const rtgpu_flat_scene *fs, int take_ownership);
+extern "C" int rtgpu_internal_counters(rtgpu_ctx *ctx, uint64_t **d_counters);
+namespace rtgpu {
+
 // host_util.cpp
 void set_global_error(const std::string &msg);
 const char *global_error();

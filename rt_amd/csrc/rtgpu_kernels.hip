@@ -1097,6 +1097,13 @@ struct rtgpu_ctx {
   // grow-only staging for the host-pointer entry points
   void *d_accum = nullptr;  size_t d_accum_bytes = 0;
   void *d_ids = nullptr;    size_t d_ids_bytes = 0;
+  // rtgpu_render_resolved: the progressive accumulation lives HERE between calls (never crosses
+  // PCIe); only the resolved 4 B/px frame is downloaded, through pinned staging
+  void *d_res_accum = nullptr;  size_t d_res_accum_bytes = 0;
+  void *d_res_rgba = nullptr;   size_t d_res_rgba_bytes = 0;
+  uint32_t *h_res_rgba = nullptr; size_t h_res_rgba_bytes = 0;  // hipHostMalloc
+  uint32_t res_w = 0, res_h = 0;
+  bool res_valid = false;       // d_res_accum holds the running sum of a res_w x res_h frame
   // rtgpu_render_begin / _poll / _end: the frame in flight on the context's own stream
   hipStream_t stream = nullptr;
   hipEvent_t ev_done = nullptr;
@@ -1146,6 +1153,7 @@ void free_scene_device(rtgpu_ctx *ctx) {
   rtgpu::free_flat_scene(&ctx->host);
   ctx->have_scene = false;
   ctx->host_stale = false;
+  ctx->res_valid = false;  // an accumulation of the old scene is not continued
 }
 
 // scratch the refits of this scene share: allocated once, freed with the scene
@@ -1281,6 +1289,9 @@ extern "C" void rtgpu_destroy(rtgpu_ctx *ctx) {
   (void)hipFree(ctx->d_planes);
   (void)hipFree(ctx->d_accum);
   (void)hipFree(ctx->d_ids);
+  (void)hipFree(ctx->d_res_accum);
+  (void)hipFree(ctx->d_res_rgba);
+  if (ctx->h_res_rgba) (void)hipHostFree(ctx->h_res_rgba);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->ev_done) (void)hipEventDestroy(ctx->ev_done);
@@ -1319,6 +1330,54 @@ extern "C" int rtgpu_upload_scene(rtgpu_ctx *ctx, const rtgpu_scene_desc *scene)
     free_scene_device(ctx);
     ctx->err = keep;
     return 2;
+  }
+  ctx->have_scene = true;
+  return 0;
+}
+
+// Internal (rtgpu_internal.h, used by group.cpp): a scene this process flattened itself goes to
+// one more GPU without being built again.  The context keeps counts and its own material table;
+// the host arrays stay the caller's unless `take_ownership` (then they are the context's host
+// mirror and freed with the scene); otherwise rtgpu_get_flat_scene copies them back on demand.
+extern "C" int rtgpu_internal_upload_flat(rtgpu_ctx *ctx, const rtgpu_flat_scene *fs, int take_ownership) {
+  if (!ctx || !fs) return 1;
+  if (ctx->pending) { ctx->err = "a frame begun with rtgpu_render_begin is pending (call rtgpu_render_end)"; return 1; }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  free_scene_device(ctx);
+  ctx->pool.trim();
+  const bool wide = fs->nodes4 && !ctx->no_wide;
+  if (upload(ctx, &ctx->d_nodes, fs->nodes, fs->n_nodes * sizeof(rtgpu_node)) ||
+      upload(ctx, &ctx->d_tris, fs->tris, (fs->n_tris + 8) * sizeof(rtgpu_tri)) ||
+      upload(ctx, &ctx->d_sphs, fs->spheres, (fs->n_spheres + 8) * sizeof(rtgpu_sph)) ||
+      upload(ctx, &ctx->d_sph_meta, fs->sphere_meta, (fs->n_spheres * 2 + 16) * sizeof(uint32_t)) ||
+      upload(ctx, &ctx->d_mats, fs->materials, fs->n_materials * sizeof(rtgpu_material)) ||
+      (fs->nodes48 && upload(ctx, &ctx->d_nodes48, fs->nodes48, fs->n_nodes * sizeof(rtgpu_node48))) ||
+      (wide && (upload(ctx, &ctx->d_nodes4, fs->nodes4, fs->n_nodes4 * sizeof(rtgpu_node4)) ||
+                upload(ctx, &ctx->d_nodes4_src, fs->nodes4_src, fs->n_nodes4 * 16)))) {
+    std::string keep = ctx->err;
+    free_scene_device(ctx);
+    ctx->err = keep;
+    return 2;
+  }
+  rtgpu_flat_scene &h = ctx->host;
+  if (take_ownership) {
+    h = *fs;
+    if (!wide) {
+      std::free((void *)h.nodes4); std::free((void *)h.nodes4_src);
+      h.nodes4 = nullptr; h.nodes4_src = nullptr; h.n_nodes4 = 0; h.max_stack4 = 0;
+    }
+  } else {
+    std::memset(&h, 0, sizeof(h));
+    h.n_nodes = fs->n_nodes; h.n_tris = fs->n_tris; h.n_spheres = fs->n_spheres; h.n_materials = fs->n_materials;
+    h.max_depth = fs->max_depth; h.build_ms = fs->build_ms;
+    if (wide) { h.n_nodes4 = fs->n_nodes4; h.max_stack4 = fs->max_stack4; }
+    const size_t mb = fs->n_materials ? (size_t)fs->n_materials * sizeof(rtgpu_material) : 64;
+    void *m = std::aligned_alloc(64, (mb + 63) / 64 * 64);
+    if (!m) { free_scene_device(ctx); ctx->err = "out of host memory for the material table"; return 2; }
+    std::memcpy(m, fs->materials, (size_t)fs->n_materials * sizeof(rtgpu_material));
+    h.materials = m;
+    ctx->host_stale = true;
   }
   ctx->have_scene = true;
   return 0;
@@ -1817,6 +1876,14 @@ extern "C" int rtgpu_debug_wave_times(rtgpu_ctx *ctx, uint64_t *out, uint64_t ma
   return 0;
 }
 
+// Internal (rtgpu_internal.h, used by group.cpp): where the context's launches keep their counters
+// ([1..6] as rtgpu_stats), so that a pipelined caller can copy them out in stream order.
+extern "C" int rtgpu_internal_counters(rtgpu_ctx *ctx, uint64_t **d_counters) {
+  if (!ctx || !d_counters) return 1;
+  *d_counters = (uint64_t *)ctx->d_counters;
+  return 0;
+}
+
 extern "C" const char *rtgpu_last_kernel_name(const rtgpu_ctx *ctx) { return ctx ? ctx->kernel_name : ""; }
 
 extern "C" int rtgpu_last_kernel_ms(rtgpu_ctx *ctx, float *ms) {
@@ -1865,6 +1932,69 @@ extern "C" int rtgpu_render(rtgpu_ctx *ctx, const rtgpu_camera *cam, const rtgpu
   if (prim_id) HIP_TRY(ctx, hipMemcpy(prim_id, ctx->d_ids, n_px * 4, hipMemcpyDeviceToHost));
   return 0;
 }
+
+// Progressive frame loop without the PCIe round trip of the float frame (include/rtgpu.h): the
+// accumulation stays in the context, the call returns the resolved 0xRRGGBBAA frame.
+extern "C" int rtgpu_render_resolved(rtgpu_ctx *ctx, const rtgpu_camera *cam, const rtgpu_settings *s,
+                                     uint32_t *rgba8, rtgpu_stats *stats) {
+  if (!ctx) return 1;
+  uint32_t ts_log2 = 0;
+  if (check_settings(ctx, cam, s, &ts_log2)) return 1;
+  if (s->flags & RTGPU_FLAG_COMPACT) { ctx->err = "rtgpu_render_resolved works on whole frames (no RTGPU_FLAG_COMPACT)"; return 1; }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const uint64_t n_px = (uint64_t)s->width * s->height;
+  if (ensure(ctx, &ctx->d_res_rgba, &ctx->d_res_rgba_bytes, n_px * 4)) return 2;
+  if (ctx->h_res_rgba_bytes < n_px * 4) {
+    if (ctx->h_res_rgba) (void)hipHostFree(ctx->h_res_rgba);
+    ctx->h_res_rgba = nullptr;
+    ctx->h_res_rgba_bytes = 0;
+    HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_res_rgba, n_px * 4, hipHostMallocDefault));
+    ctx->h_res_rgba_bytes = n_px * 4;
+  }
+  const bool fresh = !(s->flags & RTGPU_FLAG_ACCUMULATE) || !ctx->res_valid || ctx->res_w != s->width || ctx->res_h != s->height ||
+                     ctx->d_res_accum_bytes < n_px * 16;
+  if (ctx->d_res_accum_bytes < n_px * 16) {
+    ctx->res_valid = false;
+    if (ensure(ctx, &ctx->d_res_accum, &ctx->d_res_accum_bytes, n_px * 16)) return 2;
+  }
+  rtgpu_settings st = *s;
+  if (fresh) {  // nothing to continue: this frame starts the sum (a world > 1 rank leaves foreign pixels at 0)
+    st.flags &= ~(uint32_t)RTGPU_FLAG_ACCUMULATE;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_res_accum, 0, n_px * 16, ctx->stream));
+  }
+  ctx->res_valid = false;
+  int rc = rtgpu_render_device(ctx, cam, &st, ctx->d_res_accum, nullptr, ctx->stream, nullptr);
+  if (rc) { (void)hipStreamSynchronize(ctx->stream); return rc; }
+  rc = rtgpu_resolve_rgba8_device(ctx, ctx->d_res_accum, ctx->d_res_rgba, n_px, ctx->stream);
+  if (rc) { (void)hipStreamSynchronize(ctx->stream); return rc; }
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_res_rgba, ctx->d_res_rgba, n_px * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->res_w = s->width; ctx->res_h = s->height;
+  ctx->res_valid = true;
+  if (rgba8) std::memcpy(rgba8, ctx->h_res_rgba, n_px * 4);
+  if (stats) {
+    unsigned long long c[8];
+    HIP_TRY(ctx, hipMemcpy(c, ctx->d_counters, sizeof(c), hipMemcpyDeviceToHost));
+    stats->paths = c[1]; stats->rays = c[2]; stats->nodes = c[3];
+    stats->tri_tests = c[4]; stats->sphere_tests = c[5]; stats->scatters = c[6];
+  }
+  return 0;
+}
+
+extern "C" const uint32_t *rtgpu_resolved_frame(const rtgpu_ctx *ctx) {
+  return ctx && ctx->res_valid ? ctx->h_res_rgba : nullptr;
+}
+
+extern "C" int rtgpu_resident_accum(rtgpu_ctx *ctx, float *accum_rgba, uint64_t n_pixels) {
+  if (!ctx) return 1;
+  if (!ctx->res_valid) { ctx->err = "no accumulation is resident (call rtgpu_render_resolved first)"; return 1; }
+  if (!accum_rgba || n_pixels != (uint64_t)ctx->res_w * ctx->res_h) { ctx->err = "rtgpu_resident_accum: buffer is NULL or not width*height pixels of the resident frame"; return 1; }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipMemcpy(accum_rgba, ctx->d_res_accum, n_pixels * 16, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+extern "C" void rtgpu_resident_reset(rtgpu_ctx *ctx) { if (ctx) ctx->res_valid = false; }
 
 // Non-blocking form of rtgpu_render: the frame runs on the context's own stream
 // while the caller's loop keeps going (SURVEY.md §8b "blocking or begin/poll").

@@ -7,7 +7,10 @@ static_assert(sizeof(Sphere) == sizeof(::rtgpu_sphere), "Sphere layout");
 static_assert(sizeof(Triangle) == sizeof(::rtgpu_triangle), "Triangle layout");
 static_assert(sizeof(Vec4) == 16 && sizeof(Vec3) == 12, "vector layout");
 
+static_assert(sizeof(Mat4x4) == 64 && sizeof(Buffer) == 16, "Mat4x4 / Buffer layout");
+
 static ::rtgpu_ctx *gRt_Ctx = nullptr;
+static ::rtgpu_group *gRt_Group = nullptr;
 
 void rt_init_or_panic(int device_index) {
   if (gRt_Ctx) return;
@@ -60,6 +63,12 @@ Camera rt_camera_look_at(Vec3 from, Vec3 at, Vec3 up, f32 vfov_deg, f32 aspect, 
   return cam;
 }
 
+Camera rt_camera_from_basis(Mat4x4 const &camera_to_world, f32 vfov_deg, f32 aspect, f32 aperture, f32 focus_dist) {
+  Camera cam;
+  ::rtgpu_camera_from_matrix(&cam, &camera_to_world.v[0][0], vfov_deg, aspect, aperture, focus_dist);
+  return cam;
+}
+
 Render_Settings rt_default_settings(u32 width, u32 height, u32 spp, u32 max_depth) {
   Render_Settings s;
   ::rtgpu_default_settings(&s, width, height, spp, max_depth);
@@ -89,6 +98,12 @@ void rt_render_end_or_panic(Render_Stats *stats_out) {
     errf("rt: render failed: %s", ::rtgpu_last_error(gRt_Ctx));
 }
 
+void rt_render_resolved_or_panic(Camera const &cam, Render_Settings const &settings, u32 *rgba8_out,
+                                 Render_Stats *stats_out) {
+  if (::rtgpu_render_resolved(gRt_Ctx, &cam, &settings, rgba8_out, stats_out) != 0)
+    errf("rt: render failed: %s", ::rtgpu_last_error(gRt_Ctx));
+}
+
 void rt_resolve_rgba8_or_panic(Vec4 const *accum, u32 *rgba8_out, s64 pixel_count) {
   if (::rtgpu_resolve_rgba8(gRt_Ctx, (float const *)accum, rgba8_out, (uint64_t)pixel_count) != 0)
     errf("rt: resolve failed: %s", ::rtgpu_last_error(gRt_Ctx));
@@ -97,6 +112,15 @@ void rt_resolve_rgba8_or_panic(Vec4 const *accum, u32 *rgba8_out, s64 pixel_coun
 Scene rt_scene_load_obj_or_panic(char const *path) {
   ::rtgpu_scene_desc d = {};
   if (::rtgpu_scene_load_obj(path, &d) != 0) errf("rt: %s", ::rtgpu_last_error(nullptr));
+  return Scene{(Sphere *)d.spheres,     (s64)d.n_spheres,
+               (Triangle *)d.triangles, (s64)d.n_triangles,
+               (Material *)d.materials, (s64)d.n_materials};
+}
+
+Scene rt_scene_parse_obj_or_panic(Buffer file) {
+  ::rtgpu_scene_desc d = {};
+  if (::rtgpu_scene_parse_obj((char const *)file.bytes, (uint64_t)file.count, &d) != 0)
+    errf("rt: %s", ::rtgpu_last_error(nullptr));
   return Scene{(Sphere *)d.spheres,     (s64)d.n_spheres,
                (Triangle *)d.triangles, (s64)d.n_triangles,
                (Material *)d.materials, (s64)d.n_materials};
@@ -117,6 +141,45 @@ void rt_write_ppm_or_panic(char const *path, u32 const *rgba8, u32 width, u32 he
 
 void rt_write_png_or_panic(char const *path, u32 const *rgba8, u32 width, u32 height) {
   if (::rtgpu_write_png(path, rgba8, width, height) != 0) errf("rt: %s", ::rtgpu_last_error(nullptr));
+}
+
+void rt_init_multi_or_panic(int const *devices, int devices_count) {
+  if (gRt_Group) return;
+  if (::rtgpu_group_create(&gRt_Group, devices, devices_count) != 0)
+    errf("rt: cannot create the GPU group: %s", ::rtgpu_group_last_error(nullptr));
+}
+
+void rt_shutdown_multi() {
+  ::rtgpu_group_destroy(gRt_Group);
+  gRt_Group = nullptr;
+}
+
+void rt_scene_upload_multi_or_panic(Scene const &scene) {
+  ::rtgpu_scene_desc d = desc_of(scene);
+  if (::rtgpu_group_upload_scene(gRt_Group, &d, 0) != 0)
+    errf("rt: scene upload failed: %s", ::rtgpu_group_last_error(gRt_Group));
+}
+
+void rt_render_multi_or_panic(Camera const &cam, Render_Settings const &settings, Vec4 *accum_out,
+                              u32 *rgba8_out, Render_Stats *stats_out) {
+  if (::rtgpu_group_render(gRt_Group, &cam, &settings, (float *)accum_out, rgba8_out, stats_out) != 0)
+    errf("rt: render failed: %s", ::rtgpu_group_last_error(gRt_Group));
+}
+
+void rt_render_multi_begin_or_panic(Camera const &cam, Render_Settings const &settings) {
+  if (::rtgpu_group_render_begin(gRt_Group, &cam, &settings) != 0)
+    errf("rt: render failed: %s", ::rtgpu_group_last_error(gRt_Group));
+}
+
+void rt_render_multi_end_or_panic(Vec4 *accum_out, u32 *rgba8_out, Render_Stats *stats_out) {
+  if (::rtgpu_group_render_end(gRt_Group, (float *)accum_out, rgba8_out, stats_out) != 0)
+    errf("rt: render failed: %s", ::rtgpu_group_last_error(gRt_Group));
+}
+
+f32 rt_last_kernel_ms_multi(int index) {
+  f32 ms = 0.f;
+  if (::rtgpu_group_kernel_ms(gRt_Group, index, &ms) != 0) return -1.f;
+  return ms;
 }
 
 f32 rt_last_kernel_ms() {

@@ -31,6 +31,7 @@ using u8  = unsigned char;       // code/first.hpp:16-27
 using u32 = unsigned int;
 using s64 = signed long long;
 using f32 = float;
+struct Buffer { s64 count; u8 *bytes; };   // code/first.hpp:29-32
 union Vec3 {                     // code/math/vec.hxx:18-28 (xy alias omitted)
   struct { f32 x, y, z; };
   f32 v[3] = {};
@@ -40,6 +41,7 @@ union Vec4 {                     // code/math/vec.hxx:30-48
   struct { f32 r, g, b, a; };
   f32 v[4] = {};
 };
+struct Mat4x4 { f32 v[4][4]; };   // code/math/mat.hxx:2-4; row-vector convention, mat.cxx:12-20
 }  // namespace rt
 template <typename... TArgs>
 [[noreturn]] void errf(char const *fmt, TArgs... args);  // code/first.hpp:95-97
@@ -49,7 +51,8 @@ namespace rt {
 enum Material_Type : u32 {
   MATERIAL_LAMBERTIAN = RTGPU_MAT_LAMBERTIAN,
   MATERIAL_METAL      = RTGPU_MAT_METAL,      // param = fuzz
-  MATERIAL_DIELECTRIC = RTGPU_MAT_DIELECTRIC  // param = index of refraction
+  MATERIAL_DIELECTRIC = RTGPU_MAT_DIELECTRIC, // param = index of refraction
+  MATERIAL_EMISSIVE   = RTGPU_MAT_EMISSIVE    // a light ("Lights", notes/plan.md:16): emits albedo * param, ends the path
 };
 
 // Layout-identical to rtgpu_material / rtgpu_sphere / rtgpu_triangle, so a
@@ -91,6 +94,11 @@ void rt_scene_build_device_or_panic(Sphere const *d_spheres, s64 spheres_count, 
 
 [[nodiscard]] Camera rt_camera_look_at(Vec3 from, Vec3 at, Vec3 up, f32 vfov_deg, f32 aspect,
                                        f32 aperture = 0.f, f32 focus_dist = 10.f);
+// The same camera from a camera-to-world Mat4x4 in the reference's row-vector convention
+// (world = p * M, code/math/mat.cxx:12-20): rows 0..2 = right / up / back axes, row 3 = eye
+// (where translate2 puts a translation, mat.cxx:93-102); the camera looks down its -z axis.
+[[nodiscard]] Camera rt_camera_from_basis(Mat4x4 const &camera_to_world, f32 vfov_deg, f32 aspect,
+                                          f32 aperture = 0.f, f32 focus_dist = 10.f);
 [[nodiscard]] Render_Settings rt_default_settings(u32 width, u32 height, u32 spp = RT_SPP,
                                                   u32 max_depth = RT_MAX_DEPTH);
 
@@ -109,6 +117,13 @@ void rt_render_begin_or_panic(Camera const &cam, Render_Settings const &settings
 [[nodiscard]] bool rt_render_done();
 void rt_render_end_or_panic(Render_Stats *stats_out = nullptr);
 
+// The progressive frame of an interactive loop: `settings.spp` more samples, the resolved
+// 0xRRGGBBAA frame back.  The float sums stay on the GPU between calls (only 4 B per pixel
+// cross PCIe); with RTGPU_FLAG_ACCUMULATE the frame adds to them, without it (camera moved,
+// settings changed) the sum starts again.  rgba8_out: width*height u32, caller-owned.
+void rt_render_resolved_or_panic(Camera const &cam, Render_Settings const &settings, u32 *rgba8_out,
+                                 Render_Stats *stats_out = nullptr);
+
 // accum -> 0xRRGGBBAA (gamma 2), ready for a B8G8R8A8/R8G8B8A8 upload.
 void rt_resolve_rgba8_or_panic(Vec4 const *accum, u32 *rgba8_out, s64 pixel_count);
 
@@ -119,8 +134,26 @@ void rt_resolve_rgba8_or_panic(Vec4 const *accum, u32 *rgba8_out, s64 pixel_coun
 // (code/os/filesystem.hxx:4-9).  A loaded Scene owns malloc'ed arrays: release
 // with rt_scene_free (or keep it for the process lifetime, alloc_perm style).
 [[nodiscard]] Scene rt_scene_load_obj_or_panic(char const *path);
+// the same from a file already in memory (what os_read_entire_file_or_panic returns, code/first.hpp:29-32)
+[[nodiscard]] Scene rt_scene_parse_obj_or_panic(Buffer file);
 void rt_scene_free(Scene &scene);
 // rgba8: 0xRRGGBBAA, row 0 = bottom (what rt_resolve_rgba8_or_panic writes)
 void rt_write_ppm_or_panic(char const *path, u32 const *rgba8, u32 width, u32 height);
 void rt_write_png_or_panic(char const *path, u32 const *rgba8, u32 width, u32 height);
+
+// ---- several GPUs of one node (include/rtgpu.h rtgpu_group_*) ----------------
+// One worker thread per GPU inside the C layer; these calls come from the ONE thread that owns
+// the window and the D3D11 device (code/gfx/gfx.cpp:36) - the workers never touch either.
+// Tiles of settings.tile_size interleaved over the GPUs, scene replicated, one RCCL gather
+// to the first device; the frame is the one-GPU frame bit for bit.
+void rt_init_multi_or_panic(int const *devices, int devices_count);
+void rt_shutdown_multi();
+void rt_scene_upload_multi_or_panic(Scene const &scene);
+// accum_out (width*height Vec4) and rgba8_out (width*height u32) may each be null
+void rt_render_multi_or_panic(Camera const &cam, Render_Settings const &settings, Vec4 *accum_out,
+                              u32 *rgba8_out, Render_Stats *stats_out = nullptr);
+// two frames may be in flight: begin k+1 before ending k and the gather of k runs beside the trace of k+1
+void rt_render_multi_begin_or_panic(Camera const &cam, Render_Settings const &settings);
+void rt_render_multi_end_or_panic(Vec4 *accum_out, u32 *rgba8_out, Render_Stats *stats_out = nullptr);
+[[nodiscard]] f32 rt_last_kernel_ms_multi(int index);
 }  // namespace rt

@@ -2,9 +2,15 @@
 // (code/first.cpp cannot be built off Windows): the same
 // init chain and "frame loop" shape, with a PPM file where Present would be.
 //
-//   rt_headless [scene 0|1|2 | mesh.obj] [width height spp depth level out.ppm]
+//   rt_headless [--gpus N | --devices a,b,..] [--frames F] [scene 0|1|2 | mesh.obj] [width height spp depth level out.ppm]
 // A scene argument that is not a number is read as a Wavefront OBJ file and
 // framed from its bounding box.
+//   --frames F        F progressive frames of `spp` samples each (sample offsets 0, spp, 2 spp ...);
+//                     on one GPU through rt_render_resolved_or_panic: the float sums stay on the GPU
+//   --gpus N          GPUs 0..N-1 of this node behind the group API (worker thread per GPU, RCCL
+//                     tile gather to GPU 0), frames pipelined two deep
+//   --devices a,b,..  the same with an explicit device list; a device listed twice rehearses
+//                     several ranks on one GPU (tile buffers then move by device copies)
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -29,6 +35,26 @@ template <typename... TArgs>
 using namespace rt;
 
 int main(int argc, char **argv) {
+  int devices[64], n_devices = 0, frames = 0;
+  while (argc > 1 && argv[1][0] == '-' && argv[1][1] == '-') {
+    if (argc < 3) errf("%s needs a value", argv[1]);
+    if (!std::strcmp(argv[1], "--gpus")) {
+      n_devices = std::atoi(argv[2]);
+      if (n_devices < 1 || n_devices > 64) errf("--gpus 1..64");
+      for (int i = 0; i < n_devices; i++) devices[i] = i;
+    } else if (!std::strcmp(argv[1], "--devices")) {
+      for (char *tok = std::strtok(argv[2], ","); tok && n_devices < 64; tok = std::strtok(nullptr, ",")) devices[n_devices++] = std::atoi(tok);
+      if (n_devices < 1) errf("--devices a,b,...");
+    } else if (!std::strcmp(argv[1], "--frames")) {
+      frames = std::atoi(argv[2]);
+      if (frames < 1) errf("--frames >= 1");
+    } else {
+      errf("unknown option %s", argv[1]);
+    }
+    argv += 2;
+    argc -= 2;
+  }
+  bool const multi = n_devices > 0;
   u32 kind   = argc > 1 ? (u32)std::atoi(argv[1]) : 0;
   u32 width  = argc > 2 ? (u32)std::atoi(argv[2]) : 1366;  // WIN_WIDTH/HEIGHT, code/config.hpp:7-8
   u32 height = argc > 3 ? (u32)std::atoi(argv[3]) : 768;
@@ -39,7 +65,8 @@ int main(int argc, char **argv) {
 
   bool from_file = argc > 1 && (argv[1][0] < '0' || argv[1][0] > '9');
 
-  rt_init_or_panic();
+  if (multi) rt_init_multi_or_panic(devices, n_devices);
+  else rt_init_or_panic();
 
   ::rtgpu_scene_desc builtin = {};
   Camera cam;
@@ -74,7 +101,8 @@ int main(int argc, char **argv) {
                   (Triangle *)builtin.triangles, (s64)builtin.n_triangles,
                   (Material *)builtin.materials, (s64)builtin.n_materials};
   }
-  rt_scene_upload_or_panic(scene);
+  if (multi) rt_scene_upload_multi_or_panic(scene);
+  else rt_scene_upload_or_panic(scene);
 
   // alloc_perm-style: zeroed, lives until exit (code/base/memory.cxx:23-34)
   Vec4 *accum = (Vec4 *)std::calloc((size_t)width * height, sizeof(Vec4));
@@ -82,23 +110,56 @@ int main(int argc, char **argv) {
   if (!accum || !rgba) errf("out of memory for a %ux%u frame", width, height);
 
   Render_Settings settings = rt_default_settings(width, height, spp, depth);
-  Render_Stats stats;
+  Render_Stats stats = {};
   auto t0 = std::chrono::steady_clock::now();
-  // The frame loop of code/first.cpp:78-88 with the trace in flight: begin once,
-  // keep "pumping messages" until the frame is done, then collect it.
-  rt_render_begin_or_panic(cam, settings, accum);
   s64 pumped = 0;
-  while (!rt_render_done()) pumped++;  // win32_message_loop(); gfx_render(); would go here
-  rt_render_end_or_panic(&stats);
+  double kernel_ms = 0.0;
+  unsigned long long rays = 0;
+  if (multi) {
+    // frames pipelined two deep: the gather of frame k runs beside the trace of frame k+1
+    int const n_frames = frames ? frames : 1;
+    for (int f = 0; f <= n_frames; f++) {
+      if (f < n_frames) {
+        Render_Settings st = settings;
+        st.sample_offset = (u32)f * spp;
+        if (f) st.flags |= RTGPU_FLAG_ACCUMULATE;
+        rt_render_multi_begin_or_panic(cam, st);
+      }
+      if (f > 0) {
+        bool const last = f == n_frames;
+        Render_Stats fs = {};
+        rt_render_multi_end_or_panic(last ? accum : nullptr, last ? rgba : nullptr, &fs);
+        rays += fs.rays;
+      }
+    }
+    for (int i = 0; i < n_devices; i++) if ((double)rt_last_kernel_ms_multi(i) > kernel_ms) kernel_ms = rt_last_kernel_ms_multi(i);
+  } else if (frames) {
+    // the interactive loop: every iteration traces `spp` more samples and gets the resolved frame
+    for (int f = 0; f < frames; f++) {
+      Render_Settings st = settings;
+      st.sample_offset = (u32)f * spp;
+      if (f) st.flags |= RTGPU_FLAG_ACCUMULATE;
+      rt_render_resolved_or_panic(cam, st, rgba, &stats);  // win32_message_loop(); ... gfx_render(); around it
+      rays += stats.rays;
+    }
+    kernel_ms = rt_last_kernel_ms();
+  } else {
+    // The frame loop of code/first.cpp:78-88 with the trace in flight: begin once,
+    // keep "pumping messages" until the frame is done, then collect it.
+    rt_render_begin_or_panic(cam, settings, accum);
+    while (!rt_render_done()) pumped++;  // win32_message_loop(); gfx_render(); would go here
+    rt_render_end_or_panic(&stats);
+    rays = stats.rays;
+    kernel_ms = rt_last_kernel_ms();
+    rt_resolve_rgba8_or_panic(accum, rgba, (s64)width * height);
+  }
   double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-  rt_resolve_rgba8_or_panic(accum, rgba, (s64)width * height);
 
-  std::printf("scene %u: %llu spheres, %llu triangles; %ux%u, %u spp, depth %u\n", kind,
+  std::printf("scene %u: %llu spheres, %llu triangles; %ux%u, %u spp x %d frame(s), depth %u, %d GPU(s)\n", kind,
               (unsigned long long)builtin.n_spheres, (unsigned long long)builtin.n_triangles, width,
-              height, spp, depth);
-  std::printf("%llu rays, kernel %.3f ms (%.1f Mrays/s), begin..end %.3f ms incl. PCIe copies, %lld loop iterations meanwhile\n",
-              (unsigned long long)stats.rays, rt_last_kernel_ms(),
-              (double)stats.rays / (rt_last_kernel_ms() * 1e3), ms, (long long)pumped);
+              height, spp, frames ? frames : 1, depth, multi ? n_devices : 1);
+  std::printf("%llu rays in %.3f ms wall (%.1f Mrays/s incl. host copies); last trace kernel %.3f ms; %lld loop iterations meanwhile\n",
+              rays, ms, (double)rays / (ms * 1e3), kernel_ms, (long long)pumped);
 
   // where Present would be: PNG if the name says so, else PPM
   size_t const path_len = strlen(out_path);
@@ -106,6 +167,7 @@ int main(int argc, char **argv) {
   else rt_write_ppm_or_panic(out_path, rgba, width, height);
   std::printf("wrote %s\n", out_path);
   rt_scene_free(scene);
-  rt_shutdown();
+  if (multi) rt_shutdown_multi();
+  else rt_shutdown();
   return 0;
 }

@@ -23,7 +23,7 @@ def test_every_declared_symbol_is_exported(ra):
 
 
 def test_abi_version_and_struct_sizes(ra):
-    assert ra.lib.rtgpu_abi_version() == 4
+    assert ra.lib.rtgpu_abi_version() == 5
     from rt_amd import api
     assert C.sizeof(api.Camera) == 80
     assert C.sizeof(api.Settings) == 72

@@ -151,3 +151,46 @@ def test_tile_bookkeeping(ra):
         back = dist.untile_host(np.concatenate(parts), w, h, ts, world)
         assert np.array_equal(back, img)
     assert ra.compact_pixels(64, 64, 64, 5, 4) == 0     # rank >= world
+
+
+def test_camera_from_matrix_follows_the_reference_row_vector_convention(ra, oracle):
+    """rtgpu_camera_from_matrix (rt::Mat4x4, code/math/mat.cxx:12-20: world = p * M): the eye is
+    (0,0,0,1) * M and the view direction (0,0,-1,1) * M - eye, both computed with the oracle's
+    transform_point, which tests/test_oracle_kat.py pins to the REFERENCE's own
+    transformed_point on these same fixture matrices (tests/golden/ref_math.json)."""
+    import ctypes as C
+    from oracle import fptr
+    from util import f32, golden_json
+    g = golden_json("ref_math.json")
+    mats = f32(g["m"]).reshape(-1, 16)
+    out = np.zeros(4, np.float32)
+
+    def xf(p, m):
+        oracle.lib.rto_transform_point4(fptr(np.ascontiguousarray(p, np.float32)), fptr(np.ascontiguousarray(m, np.float32)), fptr(out))
+        return out.copy()
+    as_bytes = lambda cam: bytes((C.c_char * C.sizeof(cam)).from_buffer_copy(cam))
+    n = 0
+    for m in mats:
+        if not np.all(np.isfinite(m)) or np.abs(m).max() > 1e6:
+            continue
+        eye, at = xf((0, 0, 0, 1), m), xf((0, 0, -1, 1), m)
+        up = m[4:7]
+        if np.linalg.norm(np.cross(up.astype(np.float64), (eye - at)[:3].astype(np.float64))) < 1e-6:
+            continue
+        want = ra.look_at(tuple(eye[:3]), tuple(at[:3]), up=tuple(up), vfov=33.0, aspect=1.5, aperture=0.1, focus_dist=7.0)
+        got = ra.camera_from_matrix(m.reshape(4, 4), vfov=33.0, aspect=1.5, aperture=0.1, focus_dist=7.0)
+        assert as_bytes(got) == as_bytes(want)
+        assert list(got.origin) == [m[12], m[13], m[14]]          # row 3 is the translation (mat.cxx:93-102)
+        n += 1
+    assert n >= 8
+    # the textbook camera: rows = right, up, back, eye reproduce rtgpu_camera_look_at exactly
+    eye, at = np.array([13.0, 2.0, 3.0]), np.zeros(3)
+    w = (eye - at) / np.linalg.norm(eye - at)
+    u = np.cross([0, 1, 0], w); u /= np.linalg.norm(u)
+    v = np.cross(w, u)
+    M = np.zeros((4, 4), np.float32)
+    M[0, :3], M[1, :3], M[2, :3], M[3, :3], M[3, 3] = u, v, w, eye, 1
+    a, b = ra.camera_from_matrix(M, vfov=20.0), ra.look_at(tuple(eye), tuple(eye - M[2, :3].astype(np.float64)), up=tuple(M[1, :3]), vfov=20.0)
+    assert np.allclose(list(a.lower_left), list(b.lower_left), atol=1e-5) and np.allclose(list(a.horizontal), list(b.horizontal), atol=1e-5)
+    c = ra.look_at((13, 2, 3), (0, 0, 0), vfov=20.0)
+    assert np.allclose(list(a.lower_left), list(c.lower_left), atol=2e-5) and np.allclose(list(a.vertical), list(c.vertical), atol=2e-5)
