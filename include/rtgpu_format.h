@@ -74,6 +74,12 @@ typedef struct rtgpu_node4 {
   uint32_t w[24];
 } rtgpu_node4;
 #define RTGPU_NODE4_FAR 0x7F000000u /* 2^127 as float bits */
+/* Node order of the four-wide array: node 0 is the root and the first RTGPU_TOP_NODES4 nodes are
+ * the ones nearest the root, breadth first (host collapse; the GPU collapse numbers the whole
+ * tree level by level), so the top of the tree is a prefix of the array: the trace kernel keeps
+ * as much of it in LDS as fits beside the traversal stacks.  Every inner child reference names a
+ * later node. */
+#define RTGPU_TOP_NODES4 1024u
 
 /* Child reference (also the traversal-stack entry):
  *   bit 31 = 0 : inner node, bits 0..30 = node index

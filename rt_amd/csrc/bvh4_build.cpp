@@ -8,7 +8,10 @@
 // first), putting that child's two children in its place - so child order stays
 // the BVH2's left-to-right order and every box is one the BVH2 already stores.
 // Nodes are emitted parent first, children's subtrees in child order, within the top
-// of the tree and within every subtree below it (built as parallel tasks).
+// of the tree and within every subtree below it (built as parallel tasks); the final
+// numbering then puts the RTGPU_TOP_NODES4 nodes nearest the root first, breadth first, so
+// that the top of the tree is a prefix of the array (the trace kernel keeps it in LDS),
+// and leaves the others in emission order.
 #include <atomic>
 #include <cmath>
 #include <cstdlib>
@@ -198,7 +201,40 @@ rtgpu_node4 *collapse_nodes4(const rtgpu_node *nodes, uint64_t n, uint64_t *n_ou
   std::memset((char *)p + total * sizeof(rtgpu_node4), 0, bytes - total * sizeof(rtgpu_node4));
   std::memset((char *)src + total * 16, 0, src_bytes - total * 16);
   std::atomic<bool> bad{false};
-  // pieces: 0 = top part, 1 + t = task t
+  // emission index of a node's inner child (pieces: 0 = top part at 0, 1 + t = task t at base[t])
+  auto child_index = [&](size_t piece, const Tmp &t, int c) -> uint32_t {
+    const size_t at = piece == 0 ? 0 : base[piece - 1];
+    return t.task[c] ? (uint32_t)base[t.ref[c]] : (uint32_t)(at + t.ref[c]);
+  };
+  auto node_at = [&](uint32_t g, size_t *piece_out) -> const Tmp & {
+    size_t piece = 0;
+    if (g >= base[0]) {  // the task whose range holds g
+      size_t lo = 0, hi = tasks.size();
+      while (hi - lo > 1) { size_t mid = (lo + hi) / 2; (base[mid] <= g ? lo : hi) = mid; }
+      piece = lo + 1;
+    }
+    *piece_out = piece;
+    return piece == 0 ? top.out[g] : sub[piece - 1].out[g - base[piece - 1]];
+  };
+  // final numbering: emission index -> array index.  Breadth first from the root for the first
+  // RTGPU_TOP_NODES4 nodes, emission order for the rest.
+  std::vector<uint32_t> perm(total);
+  {
+    std::vector<uint32_t> order;  // emission indices of the top nodes, breadth first
+    order.reserve(RTGPU_TOP_NODES4);
+    order.push_back(0);
+    for (size_t head = 0; head < order.size() && order.size() < RTGPU_TOP_NODES4; head++) {
+      size_t piece;
+      const Tmp &t = node_at(order[head], &piece);
+      for (int c = 0; c < 4 && order.size() < RTGPU_TOP_NODES4; c++)
+        if (!(t.ref[c] & RTGPU_REF_LEAF)) order.push_back(child_index(piece, t, c));
+    }
+    std::vector<uint8_t> in_top(total, 0);
+    for (size_t k = 0; k < order.size(); k++) { perm[order[k]] = (uint32_t)k; in_top[order[k]] = 1; }
+    uint32_t next = (uint32_t)order.size();
+    for (size_t g = 0; g < total; g++)
+      if (!in_top[g]) perm[g] = next++;
+  }
   parallel_for(tasks.size() + 1, kThreads, [&](size_t piece) {
     const std::vector<Tmp> &v = piece == 0 ? top.out : sub[piece - 1].out;
     const size_t at = piece == 0 ? 0 : base[piece - 1];
@@ -206,10 +242,11 @@ rtgpu_node4 *collapse_nodes4(const rtgpu_node *nodes, uint64_t n, uint64_t *n_ou
       Tmp t = v[k];
       for (int c = 0; c < 4; c++) {
         if (t.ref[c] & RTGPU_REF_LEAF) continue;  // leaves and EMPTY
-        t.ref[c] = t.task[c] ? (uint32_t)base[t.ref[c]] : (uint32_t)(at + t.ref[c]);
+        t.ref[c] = perm[child_index(piece, v[k], c)];
       }
-      if (!pack4(t, &p[at + k])) bad = true;
-      std::memcpy(&src[4 * (at + k)], t.src, 16);
+      const size_t to = perm[at + k];
+      if (!pack4(t, &p[to])) bad = true;
+      std::memcpy(&src[4 * to], t.src, 16);
     }
   });
   if (bad) { std::free(p); std::free(src); err = fail; return nullptr; }

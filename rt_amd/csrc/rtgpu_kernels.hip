@@ -58,6 +58,11 @@ constexpr uint32_t kDone       = 0xFFFFFFFFu;  // == RTGPU_REF_EMPTY, has the le
 // MODE 2 of the trace kernel: whole tree in LDS, planes this many nodes apart (the last
 // plane's immediate ds_read offset, 3 * 16 * kSmallNodes, has to fit in 16 bits)
 constexpr int      kSmallNodes = kBlocksPerCU == 1 ? 1365 : 512;
+// MODE 5 of the trace kernel: the first kWideCached four-wide nodes (the top of the tree: both
+// collapses number it breadth first) live in LDS as six 16-byte planes this many nodes apart
+// (the last plane's immediate ds_read offset, 5 * 16 * kWideCached, has to fit in 16 bits),
+// and the traversal stacks get the rest of the LDS, deeper entries going to global memory
+constexpr int      kWideCached = 768;
 constexpr unsigned kChunk      = 64;   // work items drawn per queue atomic (one 8x8 pixel block)
 constexpr float    kTMax       = 3.402823466e+38f;  // FLT_MAX: initial closest-hit distance
 
@@ -89,6 +94,7 @@ struct KParams {
   uint32_t chunk_samples, n_chunks, plane_stride, groups_small;
   float inv_n_chunks;
 };
+constexpr size_t kCounterBytes = 256;
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 mk2(float a, float b) { f2 r = {a, b}; return r; }
@@ -270,6 +276,40 @@ struct Stack {
     if (n >= 2) { store(sp, r1); sp++; }
     return r0;
   }
+  // Overflow-capable form with a fast path (MODE 5): while NO lane of the wave is within three
+  // entries of the end of the LDS part, a step is the LDS form's straight-line code on the index
+  // sp; otherwise entry by entry as above.  `fast` is wave-uniform; the entry a pop would return
+  // is read at the start of the step like peek().
+  __device__ __forceinline__ uint32_t peek_hybrid(bool &fast) const {
+    fast = __ballot(sp + 3 > lds_entries) == 0ull;
+    uint32_t top = 0u;
+    if (fast) top = base_at[(sp - 1) * kBlock];
+    return top;
+  }
+  __device__ __forceinline__ uint32_t step4_hybrid(bool fast, int n, uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3, uint32_t top) {
+    if (fast) {
+      lds_u32 *t = base_at + (sp - 1) * kBlock;
+      t[kBlock] = n == 4 ? r3 : (n == 3 ? r2 : r1);
+      t[2 * kBlock] = n == 4 ? r2 : r1;
+      t[3 * kBlock] = r1;
+      sp += n == 0 ? -1 : n - 1;
+      return n == 0 ? top : r0;
+    }
+    if (n == 0) { sp--; return load(sp); }
+    if (n >= 4) { store(sp, r3); sp++; }
+    if (n >= 3) { store(sp, r2); sp++; }
+    if (n >= 2) { store(sp, r1); sp++; }
+    return r0;
+  }
+  __device__ __forceinline__ uint32_t pop_if_hybrid(bool fast, bool doit, uint32_t top) {
+    if (fast) {
+      sp -= doit ? 1 : 0;
+      return top;
+    }
+    uint32_t v = kDone;
+    if (doit) { sp--; v = load(sp); }
+    return v;
+  }
   // leaf step: pop if the leaf is exhausted
   __device__ __forceinline__ uint32_t pop_if(bool doit, uint32_t top) {  // top = peek() at the start of the step
     if (LDS_ONLY) {
@@ -312,12 +352,17 @@ __device__ __forceinline__ void wave_tick(unsigned lane, unsigned long long &c) 
 // the packed 48-byte nodes (rtgpu_format.h): three loads per node step instead of four -
 // every node fetch of such a tree goes to memory, and the packed form is a quarter smaller.
 // 5 and 6: as 0 and 1 over the four-wide packed nodes (rtgpu_node4): a step tests up to four
-// children with six loads, and a ray takes about half as many dependent steps.
+// children with six loads, and a ray takes about half as many dependent steps.  6 keeps the whole
+// stack in LDS; 5 gives the stack what is left beside an LDS copy of the first kWideCached nodes
+// (six planes, kWideCached nodes apart) and sends deeper stack entries to global memory: on
+// these trees the kernel is bound by the vector memory pipeline (TA / TCP / TD ~ 90 % busy, one
+// tag lookup per lane and 16-byte load), and every node step served from LDS is six fewer loads
+// per lane for it.
 template <int STATS, int REFILL, int MODE>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RTGPU_WAVES_PER_EU, RTGPU_WAVES_PER_EU)))
 void trace_kernel(const KParams P) {
   constexpr bool LDS_ONLY = MODE == 1 || MODE == 2 || MODE == 4 || MODE == 6, SMALL = MODE == 2, 
-                 PACKED = MODE == 3 || MODE == 4, WIDE = MODE >= 5;
+                 PACKED = MODE == 3 || MODE == 4, WIDE = MODE >= 5, HYBRID = MODE == 5;
   constexpr int TRIS = MODE == 2 ? 1 : kTriStep;  // triangles per leaf step (two in the LDS mode measured C2 1.4 % slower)
   // LDS: [traversal stacks: stack_lds x kBlock u32][node cache: 4 planes x n_cached float4]
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -345,7 +390,7 @@ void trace_kernel(const KParams P) {
   V3 new_dir = mk(0.f, 0.f, 1.f);  // unnormalised direction of the segment about to start
   unsigned long long n_paths = 0, n_rays = 0, n_nodes = 0, n_tris = 0, n_sphs = 0, n_scat = 0;
   unsigned long long w_outer = 0, w_shade = 0, l_shade = 0, w_gen = 0, w_node = 0, w_sph = 0, w_tri = 0,
-                     w_trav = 0, l_trav = 0;
+                     w_trav = 0, l_trav = 0, l_node = 0, l_cached = 0, w_slow = 0;
   // traversal state (survives an early exit from the traversal loop)
   V3 inv = mk(1.f, 1.f, 1.f), noi = mk(0.f, 0.f, 0.f);
   f2 inv_xy = mk2(1.f, 1.f), inv_zx = inv_xy, inv_yz = inv_xy, noi_xy = mk2(0.f, 0.f), noi_zx = noi_xy, noi_yz = noi_xy;
@@ -375,13 +420,21 @@ void trace_kernel(const KParams P) {
   // quarter j of DIFFERENT nodes, and in this layout consecutive nodes sit in
   // consecutive 16-byte bank groups (measured 56 cycles per 64-lane node fetch
   // vs 142 for node-major LDS and 181 through the vector L1, tools/ubench).
-  const uint32_t n_cached = SMALL ? P.n_cached : 0u;
+  const uint32_t n_cached = (SMALL || HYBRID) ? P.n_cached : 0u;
   const uint32_t plane = (uint32_t)kSmallNodes;  // nodes per plane
-  for (uint32_t i = tid; i < n_cached * 4u; i += kBlock) {
-    float4 v = P.nodes[i];
-    f4 w = {v.x, v.y, v.z, v.w};
-    node_cache[(i & 3u) * plane + (i >> 2)] = w;
-  }
+  if (SMALL)
+    for (uint32_t i = tid; i < n_cached * 4u; i += kBlock) {
+      float4 v = P.nodes[i];
+      f4 w = {v.x, v.y, v.z, v.w};
+      node_cache[(i & 3u) * plane + (i >> 2)] = w;
+    }
+  if (HYBRID)  // quarter j of four-wide node k -> plane j, slot k
+    for (uint32_t i = tid; i < n_cached * 6u; i += kBlock) {
+      float4 v = P.nodes[i];
+      f4 w = {v.x, v.y, v.z, v.w};
+      const uint32_t k = i / 6u;
+      node_cache[(i - k * 6u) * (uint32_t)kWideCached + k] = w;
+    }
   __syncthreads();
   const float tmin = P.tmin;
   const uint32_t seed_hash = pcg(P.seed);
@@ -695,8 +748,51 @@ void trace_kernel(const KParams P) {
             uint32_t c3;
             asm("v_lshl_add_u32 %0, %1, 1, %1" : "=v"(c3) : "v"(cur));
             const float4 *n = (const float4 *)(nodes_base + (c3 << 5));
-            const uint32_t top = stk.peek();
-            const float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3], q4 = n[4], q5 = n[5];
+            bool fast = true;
+            const uint32_t top = HYBRID ? stk.peek_hybrid(fast) : stk.peek();
+            float4 q0, q1, q2, q3, q4, q5;
+            if (HYBRID) {
+              // Lanes whose node is among the n_cached in LDS read it there (six ds_read_b128 with
+              // immediate plane offsets), the others from memory, BOTH groups in flight together.
+              // Written as one asm block because the two groups fill the same registers in
+              // disjoint lanes: hipcc, which tracks pending loads per register and not per lane,
+              // otherwise drains the global loads before it issues the LDS reads (a full memory
+              // round trip added to every step of a wave that holds both kinds).
+              f4 w0, w1, w2, w3, w4, w5;
+              unsigned long long saved;
+              const unsigned long long in_lds = __ballot(cur < n_cached);
+              if (STATS == 2) { l_node++; if (cur < n_cached) l_cached++; if (!fast) wave_tick(lane, w_slow); }
+              const uint32_t goff = c3 << 5;
+              const uint32_t laddr = (uint32_t)(uintptr_t)(node_cache + cur);
+              asm volatile(
+                  "s_mov_b64 %[sv], exec\n\t"
+                  "s_andn2_b64 exec, %[sv], %[m]\n\t"
+                  "global_load_dwordx4 %[a0], %[go], %[nb]\n\t"
+                  "global_load_dwordx4 %[a1], %[go], %[nb] offset:16\n\t"
+                  "global_load_dwordx4 %[a2], %[go], %[nb] offset:32\n\t"
+                  "global_load_dwordx4 %[a3], %[go], %[nb] offset:48\n\t"
+                  "global_load_dwordx4 %[a4], %[go], %[nb] offset:64\n\t"
+                  "global_load_dwordx4 %[a5], %[go], %[nb] offset:80\n\t"
+                  "s_and_b64 exec, %[sv], %[m]\n\t"
+                  "ds_read_b128 %[a0], %[la]\n\t"
+                  "ds_read_b128 %[a1], %[la] offset:12288\n\t"
+                  "ds_read_b128 %[a2], %[la] offset:24576\n\t"
+                  "ds_read_b128 %[a3], %[la] offset:36864\n\t"
+                  "ds_read_b128 %[a4], %[la] offset:49152\n\t"
+                  "ds_read_b128 %[a5], %[la] offset:61440\n\t"
+                  "s_mov_b64 exec, %[sv]\n\t"
+                  "s_waitcnt vmcnt(0) lgkmcnt(0)"
+                  : [a0] "=&v"(w0), [a1] "=&v"(w1), [a2] "=&v"(w2), [a3] "=&v"(w3), [a4] "=&v"(w4), [a5] "=&v"(w5),
+                    [sv] "=&s"(saved)
+                  : [go] "v"(goff), [la] "v"(laddr), [nb] "s"(nodes_base), [m] "s"(in_lds)
+                  : "memory");
+              static_assert(kWideCached * 16 == 12288, "the plane offsets in the asm above are kWideCached * 16 apart");
+              q0 = make_float4(w0.x, w0.y, w0.z, w0.w); q1 = make_float4(w1.x, w1.y, w1.z, w1.w);
+              q2 = make_float4(w2.x, w2.y, w2.z, w2.w); q3 = make_float4(w3.x, w3.y, w3.z, w3.w);
+              q4 = make_float4(w4.x, w4.y, w4.z, w4.w); q5 = make_float4(w5.x, w5.y, w5.z, w5.w);
+            } else {
+              q0 = n[0]; q1 = n[1]; q2 = n[2]; q3 = n[3]; q4 = n[4]; q5 = n[5];
+            }
             if (STATS) n_nodes++;
             // children 0,1 sit in q0..q2 and children 2,3 in q3..q5 exactly as the two
             // children of a BVH2 node sit in its first three quarters: the same six
@@ -740,7 +836,7 @@ void trace_kernel(const KParams P) {
             RTGPU_CX(k1, r1, k3, r3);
             RTGPU_CX(k1, r1, k2, r2);
 #undef RTGPU_CX
-            cur = stk.step4(n_hit, r0, r1, r2, r3, top);
+            cur = HYBRID ? stk.step4_hybrid(fast, n_hit, r0, r1, r2, r3, top) : stk.step4(n_hit, r0, r1, r2, r3, top);
           }
           if (!WIDE && (int)cur >= 0) {
             if (STATS == 2) wave_tick(lane, w_node);
@@ -817,7 +913,8 @@ void trace_kernel(const KParams P) {
           const bool at_sph = at_leaf && (cur & RTGPU_REF_SPHERE);
           const bool at_tri = at_leaf && !(cur & RTGPU_REF_SPHERE);
           const uint32_t i = RTGPU_REF_FIRST(cur);
-          const uint32_t top = stk.peek();
+          bool fast = true;
+          const uint32_t top = HYBRID ? stk.peek_hybrid(fast) : stk.peek();
           if (at_sph) {
             float4 s = *(const float4 *)(sphs_base + (i << 4));
             if (STATS) n_sphs++;
@@ -882,7 +979,7 @@ void trace_kernel(const KParams P) {
           if (at_leaf) {
             const bool last_now = left == more;
             uint32_t next = cur + (more + 1u) - ((more + 1u) << 27);  // first+1, count-1 per test
-            uint32_t popped = stk.pop_if(last_now, top);
+            uint32_t popped = HYBRID ? stk.pop_if_hybrid(fast, last_now, top) : stk.pop_if(last_now, top);
             cur = last_now ? popped : next;
           }
           n_leaf = wave_count((int)cur < -1);
@@ -936,6 +1033,10 @@ void trace_kernel(const KParams P) {
       atomicAdd(&P.counters[20], (unsigned long long)c_trav);
       atomicAdd(&P.counters[21], (unsigned long long)c_nodes);   // of c_trav: node phases
       atomicAdd(&P.counters[22], (unsigned long long)c_leaves);  // of c_trav: leaf phases
+    }
+    {  // MODE 5: lanes in node steps, of them served from the LDS copy of the top; steps on the slow stack path
+      unsigned long long a = wave_sum(l_node), b = wave_sum(l_cached), c = wave_sum(w_slow);
+      if (lane == 0) { atomicAdd(&P.counters[23], a); atomicAdd(&P.counters[24], b); atomicAdd(&P.counters[25], c); }
     }
   }
 }
@@ -1088,6 +1189,7 @@ struct rtgpu_ctx {
   int variant = 0;              // index into kVariants (refill threshold), see rtgpu_create
   int stack_lds = kStackLds;    // cap on LDS stack entries (RTGPU_STACK_LDS shrinks it for tests)
   bool no_node_cache = false;   // RTGPU_NO_NODE_CACHE=1: every node through the vector L1 (experiments)
+  bool wide_cache = false;      // RTGPU_WIDE_CACHE=1: four-wide trees with an LDS copy of their top (measured slower)
   int blocks_per_cu[2] = {0, 0};
   uint32_t *d_ovf = nullptr;    // traversal-stack overflow, sized for the largest grid
   unsigned long long *d_wave_times = nullptr;  // profile variant: 4 x u64 per wave
@@ -1214,7 +1316,7 @@ extern "C" int rtgpu_create(rtgpu_ctx **out, int device_index) {
   hipDeviceProp_t prop;
   if ((e = hipSetDevice(device_index)) != hipSuccess ||
       (e = hipGetDeviceProperties(&prop, device_index)) != hipSuccess ||
-      (e = hipMalloc((void **)&ctx->d_counters, 256)) != hipSuccess ||
+      (e = hipMalloc((void **)&ctx->d_counters, kCounterBytes)) != hipSuccess ||
       (e = hipEventCreate(&ctx->ev0)) != hipSuccess || (e = hipEventCreate(&ctx->ev1)) != hipSuccess ||
       (e = hipEventCreateWithFlags(&ctx->ev_last, hipEventDisableTiming)) != hipSuccess ||
       (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
@@ -1246,6 +1348,7 @@ extern "C" int rtgpu_create(rtgpu_ctx **out, int device_index) {
   }
   if (const char *env = std::getenv("RTGPU_NO_NODE_CACHE")) ctx->no_node_cache = std::atoi(env) != 0;
   if (const char *env = std::getenv("RTGPU_NO_WIDE")) ctx->no_wide = std::atoi(env) != 0;
+  if (const char *env = std::getenv("RTGPU_WIDE_CACHE")) ctx->wide_cache = std::atoi(env) != 0;
   if (const char *env = std::getenv("RTGPU_STACK_LDS")) {
     int want = std::atoi(env);
     if (want >= 2 && want <= kStackLds) ctx->stack_lds = want;
@@ -1739,10 +1842,16 @@ int launch_frame(rtgpu_ctx *ctx, const rtgpu_camera *cam, const rtgpu_settings *
   uint32_t stack_lds = need < 8u ? 8u : need;
   const uint32_t cap = wide ? cap4 : (uint32_t)ctx->stack_lds;  // kStackLds (the whole LDS for four-wide nodes), or RTGPU_STACK_LDS
   if (stack_lds > cap) stack_lds = cap;
-  const uint32_t stack_fit = (uint32_t)(kLdsBytes / (kBlock * sizeof(uint32_t)));      // entries the block's LDS share holds
+  uint32_t stack_fit = (uint32_t)(kLdsBytes / (kBlock * sizeof(uint32_t)));      // entries the block's LDS share holds
+  // four-wide trees: the top kWideCached nodes in LDS, the stack in what is left, deeper entries
+  // in the overflow buffer (MODE 5).  The bound need4 is a worst case few rays come near, and the
+  // vector memory pipeline is what these scenes wait for.  Not for the entry point
+  // that may not use the context's overflow buffer, nor with RTGPU_WIDE_CACHE=0 (experiments).
+  const bool wide_cache = wide && ctx->wide_cache && sc.may_allocate && kBlocksPerCU == 1;
+  if (wide_cache) stack_fit = (uint32_t)((kLdsBytes - kWideCached * (int)sizeof(rtgpu_node4)) / (kBlock * sizeof(uint32_t)));
   if (stack_lds > stack_fit) stack_lds = stack_fit;
   P.stack_lds = stack_lds;
-  P.stack_lds_only = need <= stack_lds ? 1u : 0u;
+  P.stack_lds_only = (need <= stack_lds && !wide_cache) ? 1u : 0u;
   if (!sc.may_allocate && !P.stack_lds_only) {
     ctx->err = "rtgpu_render_device_static: the tree is too deep for traversal stacks in LDS alone (the overflow stack is not part of the static scratch)";
     return 1;
@@ -1763,9 +1872,13 @@ int launch_frame(rtgpu_ctx *ctx, const rtgpu_camera *cam, const rtgpu_settings *
     if (mode == 2) { ctx->err = "internal: packed nodes on a tree that fits the LDS cache"; return 2; }
     mode += wide ? 5 : 3;
   }
+  if (wide_cache) {  // mode == 5
+    P.n_cached = (uint32_t)(ctx->host.n_nodes4 < (uint64_t)kWideCached ? ctx->host.n_nodes4 : (uint64_t)kWideCached);
+    lds_bytes = stack_bytes + (size_t)kWideCached * sizeof(rtgpu_node4);
+  }
 
   bool want_stats = (s->flags & (RTGPU_FLAG_STATS | RTGPU_FLAG_PROFILE)) != 0;
-  HIP_TRY(ctx, hipMemsetAsync(sc.counters, 0, 256, stream));
+  HIP_TRY(ctx, hipMemsetAsync(sc.counters, 0, kCounterBytes, stream));
   ctx->timed = false;
   if (n_items > 0) {
     uint64_t want = (n_items + kBlock - 1) / kBlock;
