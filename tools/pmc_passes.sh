@@ -18,6 +18,13 @@ if [ -n "$TAPASS" ]; then
   python3 tools/pmc_summary.py "$OUT"
   exit 0
 fi
+if [ -n "$QUICKMEM" ]; then  # instruction counts, lane utilisation and memory-side traffic only
+  run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY
+  run fetch FETCH_SIZE
+  run write WRITE_SIZE
+  python3 tools/pmc_summary.py "$OUT"
+  exit 0
+fi
 if [ -n "$QUICK" ]; then
   run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY
   run sq2 SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_FLAT SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INSTS_BRANCH GRBM_GUI_ACTIVE
