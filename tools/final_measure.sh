@@ -13,8 +13,10 @@ timeout -k 10 600 python3 -u -m pytest tests -m gpu -x -q --timeout 300 --timeou
 tail -3 "$OUT/pytest_gpu.log"
 timeout -k 10 300 python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
 cut -c1-400 "$OUT/bench.json"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 bench.py --cpu-spp 0 > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.log"
+# the timed C2 region alone (every launch of the headline kernel in this trace is a C2 frame), then the whole default run
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 bench.py --cpu-spp 0 --no-also > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.log"
 cut -c1-200 "$OUT/bench_under_rocprof.json"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_also" -- python3 bench.py --cpu-spp 0 > "$OUT/bench_under_rocprof_also.json" 2> "$OUT/stats_also.log"
 timeout -k 10 120 ./tools/ubench/valu_issue > "$OUT/valu_issue.txt" 2>&1
 timeout -k 10 120 ./tools/ubench/hbm_stream > "$OUT/hbm_stream.txt" 2>&1
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/calib" -- tools/ubench/fetch_calib > "$OUT/calib.log" 2>&1

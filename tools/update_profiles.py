@@ -9,7 +9,9 @@ src = os.path.join(root, "gpurun_out", tag)
 os.makedirs(dest, exist_ok=True)
 for f in glob.glob(os.path.join(src, "stats", "**", "*_kernel_stats.csv"), recursive=True)[:1]:
     shutil.copy(f, os.path.join(dest, "kernel_stats.csv"))
-for a, b in (("bench.json", "bench.json"), ("bench_under_rocprof.json", "bench_under_rocprof.json"), ("perf.log", "perf_survey.txt"),
+for f in glob.glob(os.path.join(src, "stats_also", "**", "*_kernel_stats.csv"), recursive=True)[:1]:
+    shutil.copy(f, os.path.join(dest, "kernel_stats_with_also.csv"))
+for a, b in (("bench.json", "bench.json"), ("bench_under_rocprof_also.json", "bench_under_rocprof_also.json"), ("bench_under_rocprof.json", "bench_under_rocprof.json"), ("perf.log", "perf_survey.txt"),
              ("divergence.log", "divergence.txt"), ("calib.log", "fetch_calibration.txt"), ("valu_issue.txt", "ubench_valu_issue.txt"),
              ("hbm_stream.txt", "ubench_hbm_stream.txt"), ("host_path.txt", "host_path.txt"), ("pytest_gpu.log", "pytest_gpu.txt")):
     if os.path.exists(os.path.join(src, a)):
