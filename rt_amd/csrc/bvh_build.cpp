@@ -628,7 +628,9 @@ int flatten_scene(const rtgpu_scene_desc *scene, rtgpu_flat_scene *out, std::str
     err = "out of host memory while flattening the scene";
     return 1;
   }
-  if (out->n_nodes >= RTGPU_NODE48_MIN_NODES) {
+  uint64_t wide_min = RTGPU_NODE48_MIN_NODES;
+  if (const char *env = std::getenv("RTGPU_WIDE_MIN_NODES")) wide_min = (uint64_t)std::atoll(env);  // experiments only: the oracle's validator holds the constant
+  if (out->n_nodes >= wide_min) {
     out->nodes48 = pack_nodes48((const rtgpu_node *)out->nodes, out->n_nodes, err);
     if (!out->nodes48) { free_flat_scene(out); return 1; }
     uint32_t *src4 = nullptr;

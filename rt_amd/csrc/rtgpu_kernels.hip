@@ -57,7 +57,10 @@ constexpr int      kStackOvf   = RTGPU_MAX_TREE_DEPTH + 2;  // global overflow e
 constexpr uint32_t kDone       = 0xFFFFFFFFu;  // == RTGPU_REF_EMPTY, has the leaf bit
 // MODE 2 of the trace kernel: whole tree in LDS, planes this many nodes apart (the last
 // plane's immediate ds_read offset, 3 * 16 * kSmallNodes, has to fit in 16 bits)
-constexpr int      kSmallNodes = kBlocksPerCU == 1 ? 1365 : 512;
+#ifndef RTGPU_SMALL_NODES
+#define RTGPU_SMALL_NODES (RTGPU_BLOCKS_PER_CU == 1 ? 1365 : 512)
+#endif
+constexpr int      kSmallNodes = RTGPU_SMALL_NODES;
 // MODE 5 of the trace kernel: the first kWideCached four-wide nodes (the top of the tree: both
 // collapses number it breadth first) live in LDS as six 16-byte planes this many nodes apart
 // (the last plane's immediate ds_read offset, 5 * 16 * kWideCached, has to fit in 16 bits),
@@ -1862,7 +1865,7 @@ int launch_frame(rtgpu_ctx *ctx, const rtgpu_camera *cam, const rtgpu_settings *
   size_t lds_bytes = stack_bytes;
   int mode = P.stack_lds_only ? 1 : 0;
   P.n_cached = 0;
-  if (mode == 1 && !ctx->no_node_cache && ctx->host.n_nodes <= (uint64_t)kSmallNodes &&
+  if (mode == 1 && !ctx->no_node_cache && !wide && !ctx->d_nodes48 && ctx->host.n_nodes <= (uint64_t)kSmallNodes &&
       stack_bytes + (size_t)kSmallNodes * sizeof(rtgpu_node) <= (size_t)kLdsBytes) {
     mode = 2;
     P.n_cached = (uint32_t)ctx->host.n_nodes;

@@ -14,7 +14,7 @@ if [ "$1" = build ]; then
   for cfg in "$@"; do
     set -- $cfg
     ( cd rt_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -std=c++17 -O3 -fPIC -ffp-contract=off -fno-fast-math \
-        -fno-slp-vectorize -I../../include -I. -DRTGPU_KBLOCK=$1 -DRTGPU_BLOCKS_PER_CU=$2 -DRTGPU_WAVES_PER_EU=$3 -O2 -Rpass-analysis=kernel-resource-usage -c -o build/k_exp.o rtgpu_kernels.hip 2> build/k_exp.txt &&
+        -fno-slp-vectorize -I../../include -I. -DRTGPU_KBLOCK=$1 -DRTGPU_BLOCKS_PER_CU=$2 -DRTGPU_WAVES_PER_EU=$3 $4 -O2 -Rpass-analysis=kernel-resource-usage -c -o build/k_exp.o rtgpu_kernels.hip 2> build/k_exp.txt &&
       grep -A8 -E "trace_kernelILi0ELi(16ELi2|32ELi5|32ELi6)E" build/k_exp.txt | grep -E "Function Name|VGPRs:|ScratchSize" | sed 's/.*remark: *//' &&
       /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../librtgpu_x$1x$2w$3.so build/k_exp.o \
         $(ls build/*.o | grep -v -e k_exp.o -e rtgpu_kernels.o) -lpthread -ldl )
