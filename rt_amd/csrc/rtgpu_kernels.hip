@@ -743,7 +743,11 @@ void trace_kernel(const KParams P) {
       int n_node = wave_count((int)cur >= 0);
       if (STATS == 2) { wave_tick(lane, w_trav); if ((int)cur != -1) l_trav++; }
       long long c_phase = STATS == 2 ? (long long)clock64() : 0;
-      if (3 * n_node >= 2 * n_trav) {
+      // the two votes as ONE scalar compare per step: a node step needs n_node > 0 and 3 n_node >= 2 n_trav,
+      // i.e. n_node >= ceil(2 n_trav / 3) (>= 1 since n_trav >= 1); a leaf step 3 n_leaf > n_trav, i.e.
+      // n_leaf >= floor(n_trav / 3) + 1.
+      const int node_quorum = (2 * n_trav + 2) / 3, leaf_quorum = n_trav / 3 + 1;
+      if (n_node >= node_quorum) {
         do {
           if (WIDE && (int)cur >= 0) {
             if (STATS == 2) wave_tick(lane, w_node);
@@ -907,7 +911,7 @@ void trace_kernel(const KParams P) {
             cur = stk.step(h0 && h1, !(h0 || h1), near_c, far_c, top);
           }
           n_node = wave_count((int)cur >= 0);
-        } while (n_node > 0 && 3 * n_node >= 2 * n_trav);
+        } while (n_node >= node_quorum);
         if (STATS == 2) c_nodes += (long long)clock64() - c_phase;
       } else {
         int n_leaf;
@@ -986,7 +990,7 @@ void trace_kernel(const KParams P) {
             cur = last_now ? popped : next;
           }
           n_leaf = wave_count((int)cur < -1);
-        } while (n_leaf > 0 && 3 * n_leaf > n_trav);
+        } while (n_leaf >= leaf_quorum);
         if (STATS == 2) c_leaves += (long long)clock64() - c_phase;
       }
     }
