@@ -88,6 +88,7 @@ struct KParams {
   uint32_t ts_log2, tiles_x, rank, world, n_items, flags;
   uint32_t stack_lds, stack_lds_only;
   uint32_t n_cached;  // nodes [0, n_cached) are read from the LDS copy
+  uint32_t sph_cached; // MODE 2: > 0 = the leaf-ordered spheres (this many: all of them) sit in LDS behind the node planes
   uint32_t tiles_small;  // all tile indices < 2^22: the float tile-row estimate is usable
   float inv_tiles_x;
   // chunked frame sums (rtgpu_settings.chunk_samples): n_chunks work items per pixel; with
@@ -431,6 +432,16 @@ void trace_kernel(const KParams P) {
       f4 w = {v.x, v.y, v.z, v.w};
       node_cache[(i & 3u) * plane + (i >> 2)] = w;
     }
+  // MODE 2: the leaf-ordered spheres behind the node planes when they fit: the sphere test is then an
+  // LDS read like the node fetch instead of a round trip through the vector L1
+  lds_f4 *const sph_cache = node_cache + 4 * kSmallNodes;
+  const bool sph_in_lds = SMALL && P.sph_cached != 0u;
+  if (sph_in_lds)
+    for (uint32_t i = tid; i < P.sph_cached; i += kBlock) {
+      float4 v = P.sphs[i];
+      f4 w = {v.x, v.y, v.z, v.w};
+      sph_cache[i] = w;
+    }
   if (HYBRID)  // quarter j of four-wide node k -> plane j, slot k
     for (uint32_t i = tid; i < n_cached * 6u; i += kBlock) {
       float4 v = P.nodes[i];
@@ -474,7 +485,9 @@ void trace_kernel(const KParams P) {
         uint32_t prim;
         float4 m0, m1;
         if (hit_ref & RTGPU_REF_SPHERE) {
-          float4 s = P.sphs[hit_slot];
+          float4 s;
+          if (sph_in_lds) { const f4 w = sph_cache[hit_slot]; s = make_float4(w.x, w.y, w.z, w.w); }
+          else s = P.sphs[hit_slot];
           uint2 meta = P.sph_meta[hit_slot];
           float inv_r = rcp_exact(s.w);
           n = (p - mk(s.x, s.y, s.z)) * inv_r;
@@ -923,7 +936,9 @@ void trace_kernel(const KParams P) {
           bool fast = true;
           const uint32_t top = HYBRID ? stk.peek_hybrid(fast) : stk.peek();
           if (at_sph) {
-            float4 s = *(const float4 *)(sphs_base + (i << 4));
+            float4 s;
+            if (sph_in_lds) { const f4 w = sph_cache[i]; s = make_float4(w.x, w.y, w.z, w.w); }
+            else s = *(const float4 *)(sphs_base + (i << 4));
             if (STATS) n_sphs++;
             if (STATS == 2) wave_tick(lane, w_sph);
             V3 oc = ro - mk(s.x, s.y, s.z);
@@ -1196,6 +1211,7 @@ struct rtgpu_ctx {
   int variant = 0;              // index into kVariants (refill threshold), see rtgpu_create
   int stack_lds = kStackLds;    // cap on LDS stack entries (RTGPU_STACK_LDS shrinks it for tests)
   bool no_node_cache = false;   // RTGPU_NO_NODE_CACHE=1: every node through the vector L1 (experiments)
+  bool no_sphere_cache = false; // RTGPU_NO_SPHERE_CACHE=1: MODE 2 reads spheres through L1 as before (experiments)
   bool wide_cache = false;      // RTGPU_WIDE_CACHE=1: four-wide trees with an LDS copy of their top (measured slower)
   int blocks_per_cu[2] = {0, 0};
   uint32_t *d_ovf = nullptr;    // traversal-stack overflow, sized for the largest grid
@@ -1356,6 +1372,7 @@ extern "C" int rtgpu_create(rtgpu_ctx **out, int device_index) {
   if (const char *env = std::getenv("RTGPU_NO_NODE_CACHE")) ctx->no_node_cache = std::atoi(env) != 0;
   if (const char *env = std::getenv("RTGPU_NO_WIDE")) ctx->no_wide = std::atoi(env) != 0;
   if (const char *env = std::getenv("RTGPU_WIDE_CACHE")) ctx->wide_cache = std::atoi(env) != 0;
+  if (const char *env = std::getenv("RTGPU_NO_SPHERE_CACHE")) ctx->no_sphere_cache = std::atoi(env) != 0;
   if (const char *env = std::getenv("RTGPU_STACK_LDS")) {
     int want = std::atoi(env);
     if (want >= 2 && want <= kStackLds) ctx->stack_lds = want;
@@ -1874,6 +1891,12 @@ int launch_frame(rtgpu_ctx *ctx, const rtgpu_camera *cam, const rtgpu_settings *
     mode = 2;
     P.n_cached = (uint32_t)ctx->host.n_nodes;
     lds_bytes = stack_bytes + (size_t)kSmallNodes * sizeof(rtgpu_node);
+    // the spheres too, if what is left holds them all (S0: 485 x 16 B)
+    const size_t sph_bytes = (size_t)ctx->host.n_spheres * sizeof(rtgpu_sph);
+    if (!ctx->no_sphere_cache && ctx->host.n_spheres > 0 && lds_bytes + sph_bytes <= (size_t)kLdsBytes) {
+      P.sph_cached = (uint32_t)ctx->host.n_spheres;   // the count: the kernel copies that many
+      lds_bytes += (sph_bytes + 15) / 16 * 16;
+    }
   }
   if (wide || ctx->d_nodes48) {  // never a MODE 2 tree: RTGPU_NODE48_MIN_NODES > kSmallNodes
     if (mode == 2) { ctx->err = "internal: packed nodes on a tree that fits the LDS cache"; return 2; }
