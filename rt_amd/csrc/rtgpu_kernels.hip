@@ -394,7 +394,7 @@ void trace_kernel(const KParams P) {
   V3 new_dir = mk(0.f, 0.f, 1.f);  // unnormalised direction of the segment about to start
   unsigned long long n_paths = 0, n_rays = 0, n_nodes = 0, n_tris = 0, n_sphs = 0, n_scat = 0;
   unsigned long long w_outer = 0, w_shade = 0, l_shade = 0, w_gen = 0, w_node = 0, w_sph = 0, w_tri = 0,
-                     w_trav = 0, l_trav = 0, l_node = 0, l_cached = 0, w_slow = 0;
+                     w_trav = 0, l_trav = 0, l_node = 0, l_cached = 0, w_slow = 0, t_node = 0, t_leaf = 0;
   // traversal state (survives an early exit from the traversal loop)
   V3 inv = mk(1.f, 1.f, 1.f), noi = mk(0.f, 0.f, 0.f);
   f2 inv_xy = mk2(1.f, 1.f), inv_zx = inv_xy, inv_yz = inv_xy, noi_xy = mk2(0.f, 0.f), noi_zx = noi_xy, noi_yz = noi_xy;
@@ -762,6 +762,7 @@ void trace_kernel(const KParams P) {
       const int node_quorum = (2 * n_trav + 2) / 3, leaf_quorum = n_trav / 3 + 1;
       if (n_node >= node_quorum) {
         do {
+          if (STATS == 2) { const int n_ = wave_count((int)cur != -1); if (lane == 0) t_node += (unsigned long long)n_; }
           if (WIDE && (int)cur >= 0) {
             if (STATS == 2) wave_tick(lane, w_node);
             // 96-byte node at cur * 96 = (cur * 3) << 5: six loads, four children
@@ -929,6 +930,7 @@ void trace_kernel(const KParams P) {
       } else {
         int n_leaf;
         do {
+          if (STATS == 2) { const int n_ = wave_count((int)cur != -1); if (lane == 0) t_leaf += (unsigned long long)n_; }
           const bool at_leaf = (int)cur < -1;
           const bool at_sph = at_leaf && (cur & RTGPU_REF_SPHERE);
           const bool at_tri = at_leaf && !(cur & RTGPU_REF_SPHERE);
@@ -1059,6 +1061,9 @@ void trace_kernel(const KParams P) {
     {  // MODE 5: lanes in node steps, of them served from the LDS copy of the top; steps on the slow stack path
       unsigned long long a = wave_sum(l_node), b = wave_sum(l_cached), c = wave_sum(w_slow);
       if (lane == 0) { atomicAdd(&P.counters[23], a); atomicAdd(&P.counters[24], b); atomicAdd(&P.counters[25], c); }
+      // lanes still traversing (at a node or a leaf), summed over node steps / leaf steps of the wave
+      unsigned long long d = wave_sum(t_node), e = wave_sum(t_leaf);
+      if (lane == 0) { atomicAdd(&P.counters[26], d); atomicAdd(&P.counters[27], e); }
     }
   }
 }
@@ -1250,7 +1255,13 @@ struct Variant { int refill; KernelFn fn[3][kModes]; };  // [plain, stats, profi
   {trace_kernel<S, R, 0>, trace_kernel<S, R, 1>, trace_kernel<S, R, 2>, trace_kernel<S, R, 3>, trace_kernel<S, R, 4>, \
    trace_kernel<S, R, 5>, trace_kernel<S, R, 6>}
 #define RTGPU_VARIANT(R) {R, {RTGPU_VARIANT_ROW(0, R), RTGPU_VARIANT_ROW(1, R), RTGPU_VARIANT_ROW(2, R)}}
-const Variant kVariants[] = {RTGPU_VARIANT(0), RTGPU_VARIANT(16), RTGPU_VARIANT(32)};
+#ifndef RTGPU_REFILL_SMALL
+#define RTGPU_REFILL_SMALL 16
+#endif
+#ifndef RTGPU_REFILL_LARGE
+#define RTGPU_REFILL_LARGE 32
+#endif
+const Variant kVariants[] = {RTGPU_VARIANT(0), RTGPU_VARIANT(RTGPU_REFILL_SMALL), RTGPU_VARIANT(RTGPU_REFILL_LARGE)};
 // Default refill threshold, by what bounds the scene: 16 where the whole tree
 // sits in LDS and the kernel is VALU-bound (an outer iteration is expensive, so leave
 // the traversal loop late); 32 where nodes come from memory and the time follows the

@@ -24,6 +24,8 @@ for name in sys.argv[1:] or ["c2", "c3", "c5"]:
                                            zip(("shade", "item", "gen", "setup", "traversal"), cyc))
           + f"  (of traversal: node phases {c[21] / max(1, c[20]):.3f}, leaf phases {c[22] / max(1, c[20]):.3f};"
           + f" cycles per node step {c[21] / max(1, w_node):.0f}, per leaf step {c[22] / max(1, w_sph + w_tri):.0f})"
+          + f"\n   lanes still traversing per node step {c[26] / max(1, w_node):.1f} (of them at a node {nodes / max(1, c[26]):.3f}), "
+            f"per leaf step {c[27] / max(1, w_sph + w_tri):.1f} (of them tested {(sphs + tris) / max(1, c[27]):.3f})"
           + (f"\n   {ctx.kernel_name()}: node-step lanes served from the LDS copy of the top {c[24] / max(1, c[23]):.3f}, "
              f"node steps on the slow stack path {c[25] / max(1, w_node):.4f}" if c[23] else ""), flush=True)
 ctx.close()
