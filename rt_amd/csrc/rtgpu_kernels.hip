@@ -61,6 +61,14 @@ constexpr uint32_t kDone       = 0xFFFFFFFFu;  // == RTGPU_REF_EMPTY, has the le
 #define RTGPU_SMALL_NODES (RTGPU_BLOCKS_PER_CU == 1 ? 1365 : 512)
 #endif
 constexpr int      kSmallNodes = RTGPU_SMALL_NODES;
+// MODE 7 of the trace kernel: a scene small enough to sit in LDS WHOLE - tree (planes kTinyNodes apart), leaf-ordered
+// spheres and their {id, material} pairs, triangles, materials - at compile-time distances from the node planes, so
+// that every read of the scene is a ds_read with an immediate offset and the kernel touches memory only for the
+// work queue and the pixels.  Offsets in 16-byte units from the first plane; the last array ends below 64 KiB.
+constexpr int      kTinyNodes = 512, kTinySphs = 512, kTinyTris = 16, kTinyMats = 512;
+constexpr int      kTinySphAt = 4 * kTinyNodes, kTinyTriAt = kTinySphAt + kTinySphs, kTinyMatAt = kTinyTriAt + 3 * kTinyTris,
+                   kTinyMetaAt = kTinyMatAt + 2 * kTinyMats, kTinyEnd = kTinyMetaAt + kTinySphs / 2;
+static_assert(kTinyEnd * 16 <= 65536, "MODE 7: every array within reach of a 16-bit ds_read offset");
 // MODE 5 of the trace kernel: the first kWideCached four-wide nodes (the top of the tree: both
 // collapses number it breadth first) live in LDS as six 16-byte planes this many nodes apart
 // (the last plane's immediate ds_read offset, 5 * 16 * kWideCached, has to fit in 16 bits),
@@ -88,7 +96,8 @@ struct KParams {
   uint32_t ts_log2, tiles_x, rank, world, n_items, flags;
   uint32_t stack_lds, stack_lds_only;
   uint32_t n_cached;  // nodes [0, n_cached) are read from the LDS copy
-  uint32_t sph_cached; // MODE 2: > 0 = the leaf-ordered spheres (this many: all of them) sit in LDS behind the node planes
+  uint32_t sph_cached; // MODE 2, 7: > 0 = the leaf-ordered spheres (this many: all of them) sit in LDS behind the node planes
+  uint32_t tiny_tris, tiny_mats;  // MODE 7: triangles and materials to copy to LDS (all of them)
   uint32_t tiles_small;  // all tile indices < 2^22: the float tile-row estimate is usable
   float inv_tiles_x;
   // chunked frame sums (rtgpu_settings.chunk_samples): n_chunks work items per pixel; with
@@ -170,17 +179,20 @@ __device__ __forceinline__ uint32_t pcg(uint32_t v) {
   return (w >> 22) ^ w;
 }
 
-// Draw k of a path is pcg(key + k * 0x9E3779B9); `pos` carries key + k * golden
-// incrementally (same values mod 2^32, one 32-bit multiply fewer per draw).
+// Draw k of a path is pcg(key + k * 0x9E3779B9).  pcg(v) opens with s = v * A + C, and s is affine in k:
+// the state carried is s itself, advanced by A * 0x9E3779B9 per draw (same values mod 2^32), which leaves
+// ONE 32-bit multiply per draw (v_mul_lo_u32 is quarter rate) instead of three.
 struct Rng {
-  uint32_t pos;
-  __device__ __forceinline__ void start(uint32_t key) { pos = key; }
+  uint32_t s;
+  __device__ __forceinline__ void start(uint32_t key) { s = key * 747796405u + 2891336453u; }
   __device__ __forceinline__ float u01() {
-    uint32_t h = pcg(pos);
-    pos += 0x9E3779B9u;
+    uint32_t w = ((s >> ((s >> 28) + 4u)) ^ s) * 277803737u;
+    uint32_t h = (w >> 22) ^ w;
+    s += 0xDE500ECDu;  // 747796405 * 0x9E3779B9 mod 2^32
     return (float)(h >> 8) * 0x1p-24f;
   }
 };
+static_assert((uint32_t)(747796405ull * 0x9E3779B9ull) == 0xDE500ECDu, "step of the carried pcg state");
 
 __device__ __forceinline__ float clamp_dir(float d) {
   return __builtin_fabsf(d) < 1e-30f ? __builtin_copysignf(1e-30f, d) : d;
@@ -365,9 +377,9 @@ __device__ __forceinline__ void wave_tick(unsigned lane, unsigned long long &c) 
 template <int STATS, int REFILL, int MODE>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RTGPU_WAVES_PER_EU, RTGPU_WAVES_PER_EU)))
 void trace_kernel(const KParams P) {
-  constexpr bool LDS_ONLY = MODE == 1 || MODE == 2 || MODE == 4 || MODE == 6, SMALL = MODE == 2, 
-                 PACKED = MODE == 3 || MODE == 4, WIDE = MODE >= 5, HYBRID = MODE == 5;
-  constexpr int TRIS = MODE == 2 ? 1 : kTriStep;  // triangles per leaf step (two in the LDS mode measured C2 1.4 % slower)
+  constexpr bool LDS_ONLY = MODE == 1 || MODE == 2 || MODE == 4 || MODE == 6 || MODE == 7, SMALL = MODE == 2 || MODE == 7,
+                 TINY = MODE == 7, PACKED = MODE == 3 || MODE == 4, WIDE = MODE == 5 || MODE == 6, HYBRID = MODE == 5;
+  constexpr int TRIS = SMALL ? 1 : kTriStep;  // triangles per leaf step (two in the LDS mode measured C2 1.4 % slower)
   // LDS: [traversal stacks: stack_lds x kBlock u32][node cache: 4 planes x n_cached float4]
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   uint32_t *const lds_stack = smem;
@@ -425,7 +437,7 @@ void trace_kernel(const KParams P) {
   // consecutive 16-byte bank groups (measured 56 cycles per 64-lane node fetch
   // vs 142 for node-major LDS and 181 through the vector L1, tools/ubench).
   const uint32_t n_cached = (SMALL || HYBRID) ? P.n_cached : 0u;
-  const uint32_t plane = (uint32_t)kSmallNodes;  // nodes per plane
+  constexpr uint32_t plane = (uint32_t)(TINY ? kTinyNodes : kSmallNodes);  // nodes per plane
   if (SMALL)
     for (uint32_t i = tid; i < n_cached * 4u; i += kBlock) {
       float4 v = P.nodes[i];
@@ -434,14 +446,36 @@ void trace_kernel(const KParams P) {
     }
   // MODE 2: the leaf-ordered spheres behind the node planes when they fit: the sphere test is then an
   // LDS read like the node fetch instead of a round trip through the vector L1
-  lds_f4 *const sph_cache = node_cache + 4 * kSmallNodes;
-  const bool sph_in_lds = SMALL && P.sph_cached != 0u;
+  lds_f4 *const sph_cache = node_cache + 4 * plane;
+  const bool sph_in_lds = TINY || (SMALL && P.sph_cached != 0u);
   if (sph_in_lds)
     for (uint32_t i = tid; i < P.sph_cached; i += kBlock) {
       float4 v = P.sphs[i];
       f4 w = {v.x, v.y, v.z, v.w};
       sph_cache[i] = w;
     }
+  // MODE 7: and the triangles, the materials and the spheres' {id, material} pairs
+  typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+  typedef __attribute__((address_space(3))) u2 lds_u2;
+  lds_f4 *const tri_cache = node_cache + kTinyTriAt, *const mat_cache = node_cache + kTinyMatAt;
+  lds_u2 *const meta_cache = (lds_u2 *)(node_cache + kTinyMetaAt);
+  if (TINY) {
+    for (uint32_t i = tid; i < P.tiny_tris * 3u; i += kBlock) {
+      float4 v = P.tris[i];
+      f4 w = {v.x, v.y, v.z, v.w};
+      tri_cache[i] = w;
+    }
+    for (uint32_t i = tid; i < P.tiny_mats * 2u; i += kBlock) {
+      float4 v = P.mats[i];
+      f4 w = {v.x, v.y, v.z, v.w};
+      mat_cache[i] = w;
+    }
+    for (uint32_t i = tid; i < P.sph_cached; i += kBlock) {
+      const uint2 v = P.sph_meta[i];
+      const u2 w = {v.x, v.y};
+      meta_cache[i] = w;
+    }
+  }
   if (HYBRID)  // quarter j of four-wide node k -> plane j, slot k
     for (uint32_t i = tid; i < n_cached * 6u; i += kBlock) {
       float4 v = P.nodes[i];
@@ -488,16 +522,31 @@ void trace_kernel(const KParams P) {
           float4 s;
           if (sph_in_lds) { const f4 w = sph_cache[hit_slot]; s = make_float4(w.x, w.y, w.z, w.w); }
           else s = P.sphs[hit_slot];
-          uint2 meta = P.sph_meta[hit_slot];
+          uint2 meta;
+          if (TINY) { const u2 w = meta_cache[hit_slot]; meta = make_uint2(w.x, w.y); }
+          else meta = P.sph_meta[hit_slot];
           float inv_r = rcp_exact(s.w);
           n = (p - mk(s.x, s.y, s.z)) * inv_r;
           prim = meta.x;
-          m0 = P.mats[meta.y * 2u]; m1 = P.mats[meta.y * 2u + 1u];
+          if (TINY) {
+            const f4 a = mat_cache[meta.y * 2u], b = mat_cache[meta.y * 2u + 1u];
+            m0 = make_float4(a.x, a.y, a.z, a.w); m1 = make_float4(b.x, b.y, b.z, b.w);
+          } else {
+            m0 = P.mats[meta.y * 2u]; m1 = P.mats[meta.y * 2u + 1u];
+          }
         } else {
           // the material index came with the hit: its two loads go out with the triangle's
-          const float4 *tp = P.tris + (size_t)hit_slot * (sizeof(rtgpu_tri) / 16);
-          float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
-          m0 = P.mats[hit_mat * 2u]; m1 = P.mats[hit_mat * 2u + 1u];
+          float4 t0, t1, t2;
+          if (TINY) {
+            const f4 a = tri_cache[hit_slot * 3u], b = tri_cache[hit_slot * 3u + 1u], c = tri_cache[hit_slot * 3u + 2u];
+            const f4 d = mat_cache[hit_mat * 2u], e = mat_cache[hit_mat * 2u + 1u];
+            t0 = make_float4(a.x, a.y, a.z, a.w); t1 = make_float4(b.x, b.y, b.z, b.w); t2 = make_float4(c.x, c.y, c.z, c.w);
+            m0 = make_float4(d.x, d.y, d.z, d.w); m1 = make_float4(e.x, e.y, e.z, e.w);
+          } else {
+            const float4 *tp = P.tris + (size_t)hit_slot * (sizeof(rtgpu_tri) / 16);
+            t0 = tp[0]; t1 = tp[1]; t2 = tp[2];
+            m0 = P.mats[hit_mat * 2u]; m1 = P.mats[hit_mat * 2u + 1u];
+          }
           n = normalize(cross(mk(t1.x, t1.y, t1.z), mk(t2.x, t2.y, t2.z)));
           prim = __float_as_uint(t0.w);
         }
@@ -970,8 +1019,14 @@ void trace_kernel(const KParams P) {
 #pragma unroll
             for (int k = 0; k < TRIS; k++) {
               // a lane with fewer triangles left re-reads its last one (never past the array)
-              const float4 *tq = tp + 3u * ((uint32_t)k < more ? (uint32_t)k : more);
-              rec[k][0] = tq[0]; rec[k][1] = tq[1]; rec[k][2] = tq[2];
+              if (TINY) {  // TRIS == 1
+                const f4 a = tri_cache[i3], b = tri_cache[i3 + 1u], c = tri_cache[i3 + 2u];
+                rec[k][0] = make_float4(a.x, a.y, a.z, a.w); rec[k][1] = make_float4(b.x, b.y, b.z, b.w);
+                rec[k][2] = make_float4(c.x, c.y, c.z, c.w);
+              } else {
+                const float4 *tq = tp + 3u * ((uint32_t)k < more ? (uint32_t)k : more);
+                rec[k][0] = tq[0]; rec[k][1] = tq[1]; rec[k][2] = tq[2];
+              }
             }
             if (STATS) n_tris += 1u + more;
             if (STATS == 2) wave_tick(lane, w_tri);
@@ -1216,6 +1271,7 @@ struct rtgpu_ctx {
   int variant = 0;              // index into kVariants (refill threshold), see rtgpu_create
   int stack_lds = kStackLds;    // cap on LDS stack entries (RTGPU_STACK_LDS shrinks it for tests)
   bool no_node_cache = false;   // RTGPU_NO_NODE_CACHE=1: every node through the vector L1 (experiments)
+  bool no_tiny = false;         // RTGPU_NO_TINY=1: a scene that fits LDS whole still runs MODE 2 (experiments)
   bool no_sphere_cache = false; // RTGPU_NO_SPHERE_CACHE=1: MODE 2 reads spheres through L1 as before (experiments)
   bool wide_cache = false;      // RTGPU_WIDE_CACHE=1: four-wide trees with an LDS copy of their top (measured slower)
   int blocks_per_cu[2] = {0, 0};
@@ -1249,11 +1305,11 @@ namespace {
 // code path; the threshold only changes WHEN finished lanes are refilled, never
 // what a path computes.  RTGPU_REFILL (0/16/32) selects it for experiments.
 using KernelFn = void (*)(const KParams);
-constexpr int kModes = 7;
-struct Variant { int refill; KernelFn fn[3][kModes]; };  // [plain, stats, profile][MODE 0..6 of trace_kernel]
+constexpr int kModes = 8;
+struct Variant { int refill; KernelFn fn[3][kModes]; };  // [plain, stats, profile][MODE 0..7 of trace_kernel]
 #define RTGPU_VARIANT_ROW(S, R)                                                                         \
   {trace_kernel<S, R, 0>, trace_kernel<S, R, 1>, trace_kernel<S, R, 2>, trace_kernel<S, R, 3>, trace_kernel<S, R, 4>, \
-   trace_kernel<S, R, 5>, trace_kernel<S, R, 6>}
+   trace_kernel<S, R, 5>, trace_kernel<S, R, 6>, trace_kernel<S, R, 7>}
 #define RTGPU_VARIANT(R) {R, {RTGPU_VARIANT_ROW(0, R), RTGPU_VARIANT_ROW(1, R), RTGPU_VARIANT_ROW(2, R)}}
 #ifndef RTGPU_REFILL_SMALL
 #define RTGPU_REFILL_SMALL 16
@@ -1384,6 +1440,7 @@ extern "C" int rtgpu_create(rtgpu_ctx **out, int device_index) {
   if (const char *env = std::getenv("RTGPU_NO_WIDE")) ctx->no_wide = std::atoi(env) != 0;
   if (const char *env = std::getenv("RTGPU_WIDE_CACHE")) ctx->wide_cache = std::atoi(env) != 0;
   if (const char *env = std::getenv("RTGPU_NO_SPHERE_CACHE")) ctx->no_sphere_cache = std::atoi(env) != 0;
+  if (const char *env = std::getenv("RTGPU_NO_TINY")) ctx->no_tiny = std::atoi(env) != 0;
   if (const char *env = std::getenv("RTGPU_STACK_LDS")) {
     int want = std::atoi(env);
     if (want >= 2 && want <= kStackLds) ctx->stack_lds = want;
@@ -1908,9 +1965,19 @@ int launch_frame(rtgpu_ctx *ctx, const rtgpu_camera *cam, const rtgpu_settings *
       P.sph_cached = (uint32_t)ctx->host.n_spheres;   // the count: the kernel copies that many
       lds_bytes += (sph_bytes + 15) / 16 * 16;
     }
+    // a scene that fits LDS whole (S0 does): MODE 7
+    if (!ctx->no_sphere_cache && !ctx->no_tiny && kBlocksPerCU == 1 && ctx->host.n_nodes <= (uint64_t)kTinyNodes &&
+        ctx->host.n_spheres <= (uint64_t)kTinySphs && ctx->host.n_tris <= (uint64_t)kTinyTris &&
+        ctx->host.n_materials <= (uint64_t)kTinyMats && stack_bytes + (size_t)kTinyEnd * 16 <= (size_t)kLdsBytes) {
+      mode = 7;
+      P.sph_cached = (uint32_t)ctx->host.n_spheres;
+      P.tiny_tris = (uint32_t)ctx->host.n_tris;
+      P.tiny_mats = (uint32_t)ctx->host.n_materials;
+      lds_bytes = stack_bytes + (size_t)kTinyEnd * 16;
+    }
   }
   if (wide || ctx->d_nodes48) {  // never a MODE 2 tree: RTGPU_NODE48_MIN_NODES > kSmallNodes
-    if (mode == 2) { ctx->err = "internal: packed nodes on a tree that fits the LDS cache"; return 2; }
+    if (mode == 2 || mode == 7) { ctx->err = "internal: packed nodes on a tree that fits the LDS cache"; return 2; }
     mode += wide ? 5 : 3;
   }
   if (wide_cache) {  // mode == 5
@@ -1926,7 +1993,7 @@ int launch_frame(rtgpu_ctx *ctx, const rtgpu_camera *cam, const rtgpu_settings *
     uint64_t cap = (uint64_t)ctx->num_cus * (uint64_t)ctx->blocks_per_cu[want_stats ? 1 : 0];
     unsigned grid = (unsigned)(want < cap ? want : cap);
     if ((size_t)grid * kBlock > ctx->ovf_threads) { ctx->err = "internal: grid exceeds the overflow stack"; return 2; }
-    const Variant &var = kVariants[ctx->variant >= 0 ? ctx->variant : (mode == 2 ? kVariantSmallTree : kVariantLargeTree)];
+    const Variant &var = kVariants[ctx->variant >= 0 ? ctx->variant : (mode == 2 || mode == 7 ? kVariantSmallTree : kVariantLargeTree)];
     static_assert(RTGPU_NODE48_MIN_NODES > (unsigned)kSmallNodes, "a packed tree must not fit the LDS node cache");
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
     const int inst = (s->flags & RTGPU_FLAG_PROFILE) ? 2 : want_stats ? 1 : 0;

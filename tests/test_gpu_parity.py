@@ -199,12 +199,14 @@ def _random_scene(ra, rng, n_sph, n_tri):
     return make_scene(ra, spheres=sph, triangles=tri, materials=mats)
 
 
-@pytest.mark.parametrize("seed,n_sph,n_tri", [(1, 40, 0), (2, 0, 60), (3, 150, 150), (4, 700, 900), (5, 3, 2),
-                                              (6, 1200, 1200)])
-def test_random_scenes(ra, oracle, gpu_ctx, seed, n_sph, n_tri):
+@pytest.mark.parametrize("seed,n_sph,n_tri,mode", [(1, 40, 0, 7), (2, 0, 60, 2), (3, 150, 150, 2), (4, 700, 900, None),
+                                                   (5, 3, 2, 7), (6, 1200, 1200, None), (7, 230, 16, 7), (8, 230, 17, 2),
+                                                   (9, 500, 12, 7), (10, 513, 0, 2)])
+def test_random_scenes(ra, oracle, gpu_ctx, seed, n_sph, n_tri, mode):
     """Seeded random soups of overlapping spheres and triangles with random materials,
-    seen from inside: every kernel mode (whole tree in LDS up to 1365 nodes, larger trees
-    through L1), both primitive types in one tree, rays starting inside glass."""
+    seen from inside: every kernel mode (7: the whole scene in LDS, up to 512 nodes, 512 spheres,
+    16 triangles; 2: the whole tree in LDS up to 1365 nodes; larger trees through L1), both
+    primitive types in one tree, rays starting inside glass."""
     rng = np.random.default_rng(seed)
     scene = _random_scene(ra, rng, n_sph, n_tri)
     cam = ra.look_at(tuple(rng.uniform(-1, 1, 3)), tuple(rng.uniform(-3, 3, 3)), vfov=70.0, aspect=96 / 64)
@@ -213,6 +215,8 @@ def test_random_scenes(ra, oracle, gpu_ctx, seed, n_sph, n_tri):
     assert np.array_equal(ia, ib)
     assert_bit_equal(a, b, f"random scene {seed}")
     assert sa == sb and sa["rays"] >= 96 * 64 * 3
+    if mode is not None:
+        assert gpu_ctx.kernel_name().endswith(f",{mode}>"), gpu_ctx.kernel_name()
 
 
 def test_scene_replacement(ra, oracle, gpu_ctx):
