@@ -61,6 +61,17 @@ constexpr uint32_t kDone       = 0xFFFFFFFFu;  // == RTGPU_REF_EMPTY, has the le
 #define RTGPU_SMALL_NODES (RTGPU_BLOCKS_PER_CU == 1 ? 1365 : 512)
 #endif
 constexpr int      kSmallNodes = RTGPU_SMALL_NODES;
+// MODE 8 (two work items per lane, an experiment): a shading pass for the second slots runs while this many lanes
+// hold a result there; lanes exchange their slots mid-round from this many up; the round ends below this many
+#ifndef RTGPU_DUAL_PASS_MIN
+#define RTGPU_DUAL_PASS_MIN 24
+#endif
+#ifndef RTGPU_DUAL_SWAP_MIN
+#define RTGPU_DUAL_SWAP_MIN 8
+#endif
+#ifndef RTGPU_DUAL_REFILL
+#define RTGPU_DUAL_REFILL 16
+#endif
 // MODE 7 of the trace kernel: a scene small enough to sit in LDS WHOLE - tree (planes kTinyNodes apart), leaf-ordered
 // spheres and their {id, material} pairs, triangles, materials - at compile-time distances from the node planes, so
 // that every read of the scene is a ds_read with an immediate offset and the kernel touches memory only for the
@@ -377,8 +388,9 @@ __device__ __forceinline__ void wave_tick(unsigned lane, unsigned long long &c) 
 template <int STATS, int REFILL, int MODE>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RTGPU_WAVES_PER_EU, RTGPU_WAVES_PER_EU)))
 void trace_kernel(const KParams P) {
-  constexpr bool LDS_ONLY = MODE == 1 || MODE == 2 || MODE == 4 || MODE == 6 || MODE == 7, SMALL = MODE == 2 || MODE == 7,
-                 TINY = MODE == 7, PACKED = MODE == 3 || MODE == 4, WIDE = MODE == 5 || MODE == 6, HYBRID = MODE == 5;
+  constexpr bool LDS_ONLY = MODE == 1 || MODE == 2 || MODE == 4 || MODE == 6 || MODE >= 7, SMALL = MODE == 2 || MODE >= 7,
+                 TINY = MODE >= 7, DUAL = MODE == 8, PACKED = MODE == 3 || MODE == 4, WIDE = MODE == 5 || MODE == 6,
+                 HYBRID = MODE == 5;
   constexpr int TRIS = SMALL ? 1 : kTriStep;  // triangles per leaf step (two in the LDS mode measured C2 1.4 % slower)
   // LDS: [traversal stacks: stack_lds x kBlock u32][node cache: 4 planes x n_cached float4]
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -431,6 +443,19 @@ void trace_kernel(const KParams P) {
   stk.sp = 1;
   stk.lds_entries = (int)P.stack_lds;
   lds_stack[tid] = kDone;  // sentinel under every lane's stack (never overwritten)
+  // MODE 8 (experiment, RTGPU_DUAL=1): every lane owns TWO work items.  Slot P is the one in the registers above;
+  // slot Q keeps its path state in the registers below and its ray (origin | tbest, direction | hit) in a 32-byte
+  // LDS record.  A lane whose traversal ends while its other slot holds a ray ready to go exchanges the two in the
+  // middle of a traversal round (swap_slots) instead of idling to the round's end; the results wait in the record
+  // for the next shading pass.  Only one of the two rays is ever in mid-traversal (the lane has one stack).
+  bool q_alive = false, q_done = false, q_have_pixel = false, q_pixel_valid = false;
+  uint32_t q_px = 0, q_py = 0, q_out_index = 0, q_sample = 0, q_sample_end = 0, q_chunk = 0, q_bounce = 0,
+           q_first_id = RTGPU_NO_HIT;
+  V3 q_sum = mk(0.f, 0.f, 0.f), q_thr = mk(1.f, 1.f, 1.f);
+  Rng q_rng = {0u};
+  uint32_t qcur = kDone, q_hit_mat = 0u;
+  typename Stack<LDS_ONLY>::lds_u32 *q_top = stk.base_at;
+  unsigned long long w_swap = 0, l_swap = 0;
   // LDS copy of the n_cached nodes nearest the root (the builder numbers them
   // breadth-first), as four planes [16-byte quarter][node]: lanes of a wave read
   // quarter j of DIFFERENT nodes, and in this layout consecutive nodes sit in
@@ -483,6 +508,37 @@ void trace_kernel(const KParams P) {
       const uint32_t k = i / 6u;
       node_cache[(i - k * 6u) * (uint32_t)kWideCached + k] = w;
     }
+  lds_f4 *const rec = node_cache + kTinyEnd + tid;  // MODE 8: [2][kBlock] records behind the scene
+  if (DUAL) {
+    const f4 z = {0.f, 0.f, 0.f, 0.f};
+    rec[0] = z;
+    rec[kBlock] = z;
+  }
+  auto swap_slots = [&](bool doit) __attribute__((always_inline)) {
+    if (STATS == 2) { wave_tick(lane, w_swap); if (doit) l_swap++; }
+    if (doit) {
+      const f4 a = rec[0], b = rec[kBlock];
+      const f4 na = {ro.x, ro.y, ro.z, tbest}, nb = {rd.x, rd.y, rd.z, __uint_as_float(hit_ref)};
+      rec[0] = na;
+      rec[kBlock] = nb;
+      ro = mk(a.x, a.y, a.z); tbest = a.w;
+      rd = mk(b.x, b.y, b.z); hit_ref = __float_as_uint(b.w);
+#define RTGPU_SW(x, y) do { auto t_ = x; x = y; y = t_; } while (0)
+      RTGPU_SW(hit_mat, q_hit_mat); RTGPU_SW(cur, qcur); RTGPU_SW(stk.top_at, q_top);
+      RTGPU_SW(px, q_px); RTGPU_SW(py, q_py); RTGPU_SW(out_index, q_out_index); RTGPU_SW(sample, q_sample);
+      RTGPU_SW(sample_end, q_sample_end); RTGPU_SW(chunk, q_chunk); RTGPU_SW(bounce, q_bounce);
+      RTGPU_SW(first_id, q_first_id); RTGPU_SW(sum.x, q_sum.x); RTGPU_SW(sum.y, q_sum.y); RTGPU_SW(sum.z, q_sum.z);
+      RTGPU_SW(thr.x, q_thr.x); RTGPU_SW(thr.y, q_thr.y); RTGPU_SW(thr.z, q_thr.z); RTGPU_SW(rng.s, q_rng.s);
+      RTGPU_SW(alive, q_alive); RTGPU_SW(done, q_done); RTGPU_SW(have_pixel, q_have_pixel);
+      RTGPU_SW(pixel_valid, q_pixel_valid);
+#undef RTGPU_SW
+      // what (3) derived from the ray: the same operations on the same values
+      inv = mk(rcp_fast(clamp_dir(rd.x)), rcp_fast(clamp_dir(rd.y)), rcp_fast(clamp_dir(rd.z)));
+      noi = mk(-(ro.x * inv.x), -(ro.y * inv.y), -(ro.z * inv.z));
+      inv_xy = mk2(inv.x, inv.y); inv_zx = mk2(inv.z, inv.x); inv_yz = mk2(inv.y, inv.z);
+      noi_xy = mk2(noi.x, noi.y); noi_zx = mk2(noi.z, noi.x); noi_yz = mk2(noi.y, noi.z);
+    }
+  };
   __syncthreads();
   const float tmin = P.tmin;
   const uint32_t seed_hash = pcg(P.seed);
@@ -499,6 +555,15 @@ void trace_kernel(const KParams P) {
 
   unsigned long long n_after_dry = 0;
   for (;;) {
+    // MODE 8: shading passes while enough lanes hold a result in their other slot; a lane whose slot P needs
+    // nothing brings slot Q in first (parking a ray in mid-traversal in the record if it has to)
+    bool again = false;  // wave-uniform
+    do {
+    if (DUAL) {
+      const bool need_p = alive ? cur == kDone : !done;
+      const bool need_q = q_alive ? qcur == kDone : !q_done;
+      swap_slots(need_q && !need_p);
+    }
     // ---- (1) shade the rays whose traversal has finished (rows a6, a8) ----------
     if (STATS == 2) { wave_tick(lane, w_outer); if (queue_dry) n_after_dry++; }
     if (alive && cur == kDone) {
@@ -767,7 +832,6 @@ void trace_kernel(const KParams P) {
       n_paths++;
     }
     SECTION_END(c_gen);
-    if (__ballot(alive) == 0ull) break;  // done implies !alive: the whole wave is dry
 
     // ---- (3) start the traversal of every new segment --------------------------
     if (alive && cur == kDone) {
@@ -783,6 +847,11 @@ void trace_kernel(const KParams P) {
       stk.reset();
       n_rays++;
     }
+    if (DUAL) again = wave_count(q_alive ? qcur == kDone : !q_done) >= RTGPU_DUAL_PASS_MIN;
+    } while (DUAL && again);
+    // a parked ray owns the lane's stack: it goes back to the registers (slot P holds a fresh ray or nothing)
+    if (DUAL) swap_slots(qcur != kDone && qcur != 0u);
+    if (__ballot(alive || (DUAL && q_alive)) == 0ull) break;  // done implies !alive: the whole wave is dry
 
     SECTION_END(c_setup);
     // ---- (4) closest hit: ordered stack traversal (rows a3-a5) ------------------
@@ -798,10 +867,19 @@ void trace_kernel(const KParams P) {
     // values (possibly inf/NaN) that fail the final comparisons, exactly where
     // the oracle returns early.
     const int n_entry = wave_count(cur != kDone);
+    bool swapped = false;  // wave-uniform (MODE 8)
     for (;;) {
+      if (DUAL) {  // lanes that are through and hold a fresh ray in slot Q start it now
+        const bool can = cur == kDone && q_alive && qcur == 0u;
+        const int n_can = wave_count(can);
+        if (n_can >= RTGPU_DUAL_SWAP_MIN || (n_can > 0 && __ballot((int)cur != -1) == 0ull)) {
+          swap_slots(can);
+          swapped = true;
+        }
+      }
       // reference read as a signed int: inner node >= 0; leaf < -1; kDone == -1
       const int n_trav = wave_count((int)cur != -1);
-      if (n_trav == 0 || (n_trav < REFILL && n_trav < n_entry)) break;  // wave-uniform
+      if (n_trav == 0 || (n_trav < (DUAL ? RTGPU_DUAL_REFILL : REFILL) && (n_trav < n_entry || swapped))) break;  // wave-uniform
       int n_node = wave_count((int)cur >= 0);
       if (STATS == 2) { wave_tick(lane, w_trav); if ((int)cur != -1) l_trav++; }
       long long c_phase = STATS == 2 ? (long long)clock64() : 0;
@@ -1119,6 +1197,9 @@ void trace_kernel(const KParams P) {
       // lanes still traversing (at a node or a leaf), summed over node steps / leaf steps of the wave
       unsigned long long d = wave_sum(t_node), e = wave_sum(t_leaf);
       if (lane == 0) { atomicAdd(&P.counters[26], d); atomicAdd(&P.counters[27], e); }
+      // MODE 8: slot exchanges of a wave, lanes that took part
+      unsigned long long f = wave_sum(w_swap), g = wave_sum(l_swap);
+      if (lane == 0) { atomicAdd(&P.counters[28], f); atomicAdd(&P.counters[29], g); }
     }
   }
 }
@@ -1271,6 +1352,7 @@ struct rtgpu_ctx {
   int variant = 0;              // index into kVariants (refill threshold), see rtgpu_create
   int stack_lds = kStackLds;    // cap on LDS stack entries (RTGPU_STACK_LDS shrinks it for tests)
   bool no_node_cache = false;   // RTGPU_NO_NODE_CACHE=1: every node through the vector L1 (experiments)
+  bool dual = false;            // RTGPU_DUAL=1: MODE 8 instead of 7 (experiment)
   bool no_tiny = false;         // RTGPU_NO_TINY=1: a scene that fits LDS whole still runs MODE 2 (experiments)
   bool no_sphere_cache = false; // RTGPU_NO_SPHERE_CACHE=1: MODE 2 reads spheres through L1 as before (experiments)
   bool wide_cache = false;      // RTGPU_WIDE_CACHE=1: four-wide trees with an LDS copy of their top (measured slower)
@@ -1305,11 +1387,11 @@ namespace {
 // code path; the threshold only changes WHEN finished lanes are refilled, never
 // what a path computes.  RTGPU_REFILL (0/16/32) selects it for experiments.
 using KernelFn = void (*)(const KParams);
-constexpr int kModes = 8;
-struct Variant { int refill; KernelFn fn[3][kModes]; };  // [plain, stats, profile][MODE 0..7 of trace_kernel]
+constexpr int kModes = 9;
+struct Variant { int refill; KernelFn fn[3][kModes]; };  // [plain, stats, profile][MODE 0..8 of trace_kernel]
 #define RTGPU_VARIANT_ROW(S, R)                                                                         \
   {trace_kernel<S, R, 0>, trace_kernel<S, R, 1>, trace_kernel<S, R, 2>, trace_kernel<S, R, 3>, trace_kernel<S, R, 4>, \
-   trace_kernel<S, R, 5>, trace_kernel<S, R, 6>, trace_kernel<S, R, 7>}
+   trace_kernel<S, R, 5>, trace_kernel<S, R, 6>, trace_kernel<S, R, 7>, trace_kernel<S, R, 8>}
 #define RTGPU_VARIANT(R) {R, {RTGPU_VARIANT_ROW(0, R), RTGPU_VARIANT_ROW(1, R), RTGPU_VARIANT_ROW(2, R)}}
 #ifndef RTGPU_REFILL_SMALL
 #define RTGPU_REFILL_SMALL 16
@@ -1441,6 +1523,7 @@ extern "C" int rtgpu_create(rtgpu_ctx **out, int device_index) {
   if (const char *env = std::getenv("RTGPU_WIDE_CACHE")) ctx->wide_cache = std::atoi(env) != 0;
   if (const char *env = std::getenv("RTGPU_NO_SPHERE_CACHE")) ctx->no_sphere_cache = std::atoi(env) != 0;
   if (const char *env = std::getenv("RTGPU_NO_TINY")) ctx->no_tiny = std::atoi(env) != 0;
+  if (const char *env = std::getenv("RTGPU_DUAL")) ctx->dual = std::atoi(env) != 0;
   if (const char *env = std::getenv("RTGPU_STACK_LDS")) {
     int want = std::atoi(env);
     if (want >= 2 && want <= kStackLds) ctx->stack_lds = want;
@@ -1974,10 +2057,14 @@ int launch_frame(rtgpu_ctx *ctx, const rtgpu_camera *cam, const rtgpu_settings *
       P.tiny_tris = (uint32_t)ctx->host.n_tris;
       P.tiny_mats = (uint32_t)ctx->host.n_materials;
       lds_bytes = stack_bytes + (size_t)kTinyEnd * 16;
+      if (ctx->dual && lds_bytes + 2u * 16u * kBlock <= (size_t)kLdsBytes) {  // experiment: two work items per lane
+        mode = 8;
+        lds_bytes += 2u * 16u * kBlock;
+      }
     }
   }
   if (wide || ctx->d_nodes48) {  // never a MODE 2 tree: RTGPU_NODE48_MIN_NODES > kSmallNodes
-    if (mode == 2 || mode == 7) { ctx->err = "internal: packed nodes on a tree that fits the LDS cache"; return 2; }
+    if (mode == 2 || mode >= 7) { ctx->err = "internal: packed nodes on a tree that fits the LDS cache"; return 2; }
     mode += wide ? 5 : 3;
   }
   if (wide_cache) {  // mode == 5
@@ -1993,7 +2080,7 @@ int launch_frame(rtgpu_ctx *ctx, const rtgpu_camera *cam, const rtgpu_settings *
     uint64_t cap = (uint64_t)ctx->num_cus * (uint64_t)ctx->blocks_per_cu[want_stats ? 1 : 0];
     unsigned grid = (unsigned)(want < cap ? want : cap);
     if ((size_t)grid * kBlock > ctx->ovf_threads) { ctx->err = "internal: grid exceeds the overflow stack"; return 2; }
-    const Variant &var = kVariants[ctx->variant >= 0 ? ctx->variant : (mode == 2 || mode == 7 ? kVariantSmallTree : kVariantLargeTree)];
+    const Variant &var = kVariants[ctx->variant >= 0 ? ctx->variant : (mode == 2 || mode >= 7 ? kVariantSmallTree : kVariantLargeTree)];
     static_assert(RTGPU_NODE48_MIN_NODES > (unsigned)kSmallNodes, "a packed tree must not fit the LDS node cache");
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
     const int inst = (s->flags & RTGPU_FLAG_PROFILE) ? 2 : want_stats ? 1 : 0;

@@ -27,5 +27,7 @@ for name in sys.argv[1:] or ["c2", "c3", "c5"]:
           + f"\n   lanes still traversing per node step {c[26] / max(1, w_node):.1f} (of them at a node {nodes / max(1, c[26]):.3f}), "
             f"per leaf step {c[27] / max(1, w_sph + w_tri):.1f} (of them tested {(sphs + tris) / max(1, c[27]):.3f})"
           + (f"\n   {ctx.kernel_name()}: node-step lanes served from the LDS copy of the top {c[24] / max(1, c[23]):.3f}, "
-             f"node steps on the slow stack path {c[25] / max(1, w_node):.4f}" if c[23] else ""), flush=True)
+             f"node steps on the slow stack path {c[25] / max(1, w_node):.4f}" if c[23] else "")
+          + (f"\n   {ctx.kernel_name()}: slot exchanges per 64 rays {c[28] * 64 / rays:.2f}, lanes per exchange {c[29] / max(1, c[28]):.1f}"
+             if c[28] else ""), flush=True)
 ctx.close()
