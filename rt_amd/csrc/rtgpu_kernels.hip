@@ -391,6 +391,11 @@ void trace_kernel(const KParams P) {
   constexpr bool LDS_ONLY = MODE == 1 || MODE == 2 || MODE == 4 || MODE == 6 || MODE >= 7, SMALL = MODE == 2 || MODE >= 7,
                  TINY = MODE >= 7, DUAL = MODE == 8, PACKED = MODE == 3 || MODE == 4, WIDE = MODE == 5 || MODE == 6,
                  HYBRID = MODE == 5;
+#ifdef RTGPU_NO_HIT_NORMAL  // experiments: shading fetches the triangle again
+  constexpr bool KEEP_N = false;
+#else
+  constexpr bool KEEP_N = !SMALL;
+#endif
   constexpr int TRIS = SMALL ? 1 : kTriStep;  // triangles per leaf step (two in the LDS mode measured C2 1.4 % slower)
   // LDS: [traversal stacks: stack_lds x kBlock u32][node cache: 4 planes x n_cached float4]
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -430,6 +435,10 @@ void trace_kernel(const KParams P) {
   // material index of the closest TRIANGLE hit so far, taken from the record the test has in
   // registers: shading then fetches the material together with the triangle instead of after it
   uint32_t hit_mat = 0u;
+  // trees in memory (not MODE 2, 7, 8): the closest triangle's e1 x e2 and id are kept too, so that shading does not
+  // fetch the record again (a dependent round trip through the vector memory pipeline per shading pass)
+  V3 hit_n = mk(0.f, 0.f, 1.f);
+  uint32_t hit_prim = 0u;
   unsigned pool_next = 0, pool_end = 0;  // wave-local slice of the work queue (wave-uniform)
   // wave-uniform description of the group the pool was drawn from (see (2))
   uint32_t g_px = 0, g_py = 0, g_out = 0, g_row = 0, g_chunk = 0, g_sample = 0, g_sample_end = 0;
@@ -607,13 +616,19 @@ void trace_kernel(const KParams P) {
             const f4 d = mat_cache[hit_mat * 2u], e = mat_cache[hit_mat * 2u + 1u];
             t0 = make_float4(a.x, a.y, a.z, a.w); t1 = make_float4(b.x, b.y, b.z, b.w); t2 = make_float4(c.x, c.y, c.z, c.w);
             m0 = make_float4(d.x, d.y, d.z, d.w); m1 = make_float4(e.x, e.y, e.z, e.w);
-          } else {
+            n = normalize(cross(mk(t1.x, t1.y, t1.z), mk(t2.x, t2.y, t2.z)));
+            prim = __float_as_uint(t0.w);
+          } else if (!KEEP_N) {
             const float4 *tp = P.tris + (size_t)hit_slot * (sizeof(rtgpu_tri) / 16);
             t0 = tp[0]; t1 = tp[1]; t2 = tp[2];
             m0 = P.mats[hit_mat * 2u]; m1 = P.mats[hit_mat * 2u + 1u];
+            n = normalize(cross(mk(t1.x, t1.y, t1.z), mk(t2.x, t2.y, t2.z)));
+            prim = __float_as_uint(t0.w);
+          } else {
+            m0 = P.mats[hit_mat * 2u]; m1 = P.mats[hit_mat * 2u + 1u];
+            n = normalize(hit_n);
+            prim = hit_prim;
           }
-          n = normalize(cross(mk(t1.x, t1.y, t1.z), mk(t2.x, t2.y, t2.z)));
-          prim = __float_as_uint(t0.w);
         }
         if (bounce == 0 && sample == 0) first_id = prim;
         float dn = dot(rd, n);
@@ -1129,6 +1144,7 @@ void trace_kernel(const KParams P) {
                   tbest = t;
                   hit_ref = cur + (uint32_t)k - ((uint32_t)k << 27);
                   hit_mat = __float_as_uint(b.w);
+                  if (KEEP_N) { hit_n = cross(e1, e2); hit_prim = __float_as_uint(a.w); }
                 }
               }
             }
