@@ -388,9 +388,9 @@ __device__ __forceinline__ void wave_tick(unsigned lane, unsigned long long &c) 
 template <int STATS, int REFILL, int MODE>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RTGPU_WAVES_PER_EU, RTGPU_WAVES_PER_EU)))
 void trace_kernel(const KParams P) {
-  constexpr bool LDS_ONLY = MODE == 1 || MODE == 2 || MODE == 4 || MODE == 6 || MODE >= 7, SMALL = MODE == 2 || MODE >= 7,
-                 TINY = MODE >= 7, DUAL = MODE == 8, PACKED = MODE == 3 || MODE == 4, WIDE = MODE == 5 || MODE == 6,
-                 HYBRID = MODE == 5;
+  constexpr bool LDS_ONLY = MODE == 1 || MODE == 2 || MODE == 4 || (MODE >= 6 && MODE <= 9), SMALL = MODE == 2 || MODE == 7 || MODE == 8,
+                 TINY = MODE == 7 || MODE == 8, DUAL = MODE >= 8, PACKED = MODE == 3 || MODE == 4,
+                 WIDE = MODE == 5 || MODE == 6 || MODE >= 9, HYBRID = MODE == 5 || MODE == 10;
 #ifdef RTGPU_NO_HIT_NORMAL  // experiments: shading fetches the triangle again
   constexpr bool KEEP_N = false;
 #else
@@ -462,7 +462,9 @@ void trace_kernel(const KParams P) {
            q_first_id = RTGPU_NO_HIT;
   V3 q_sum = mk(0.f, 0.f, 0.f), q_thr = mk(1.f, 1.f, 1.f);
   Rng q_rng = {0u};
-  uint32_t qcur = kDone, q_hit_mat = 0u;
+  uint32_t qcur = kDone, q_hit_mat = 0u, q_hit_prim = 0u;
+  int q_sp = 1;
+  V3 q_hit_n = mk(0.f, 0.f, 1.f);
   typename Stack<LDS_ONLY>::lds_u32 *q_top = stk.base_at;
   unsigned long long w_swap = 0, l_swap = 0;
   // LDS copy of the n_cached nodes nearest the root (the builder numbers them
@@ -517,7 +519,7 @@ void trace_kernel(const KParams P) {
       const uint32_t k = i / 6u;
       node_cache[(i - k * 6u) * (uint32_t)kWideCached + k] = w;
     }
-  lds_f4 *const rec = node_cache + kTinyEnd + tid;  // MODE 8: [2][kBlock] records behind the scene
+  lds_f4 *const rec = node_cache + (TINY ? kTinyEnd : 0) + tid;  // MODE 8, 9: [2][kBlock] records behind the scene / the stacks
   if (DUAL) {
     const f4 z = {0.f, 0.f, 0.f, 0.f};
     rec[0] = z;
@@ -533,7 +535,8 @@ void trace_kernel(const KParams P) {
       ro = mk(a.x, a.y, a.z); tbest = a.w;
       rd = mk(b.x, b.y, b.z); hit_ref = __float_as_uint(b.w);
 #define RTGPU_SW(x, y) do { auto t_ = x; x = y; y = t_; } while (0)
-      RTGPU_SW(hit_mat, q_hit_mat); RTGPU_SW(cur, qcur); RTGPU_SW(stk.top_at, q_top);
+      RTGPU_SW(hit_mat, q_hit_mat); RTGPU_SW(cur, qcur); RTGPU_SW(stk.top_at, q_top); RTGPU_SW(stk.sp, q_sp);
+      if (KEEP_N) { RTGPU_SW(hit_n.x, q_hit_n.x); RTGPU_SW(hit_n.y, q_hit_n.y); RTGPU_SW(hit_n.z, q_hit_n.z); RTGPU_SW(hit_prim, q_hit_prim); }
       RTGPU_SW(px, q_px); RTGPU_SW(py, q_py); RTGPU_SW(out_index, q_out_index); RTGPU_SW(sample, q_sample);
       RTGPU_SW(sample_end, q_sample_end); RTGPU_SW(chunk, q_chunk); RTGPU_SW(bounce, q_bounce);
       RTGPU_SW(first_id, q_first_id); RTGPU_SW(sum.x, q_sum.x); RTGPU_SW(sum.y, q_sum.y); RTGPU_SW(sum.z, q_sum.z);
@@ -1401,25 +1404,26 @@ namespace {
 
 // Kernel variants: {refill threshold} x {plain, instrumented}.  One source, one
 // code path; the threshold only changes WHEN finished lanes are refilled, never
-// what a path computes.  RTGPU_REFILL (0/16/32) selects it for experiments.
+// what a path computes.  RTGPU_REFILL (0/16/40) selects it for experiments.
 using KernelFn = void (*)(const KParams);
-constexpr int kModes = 9;
-struct Variant { int refill; KernelFn fn[3][kModes]; };  // [plain, stats, profile][MODE 0..8 of trace_kernel]
+constexpr int kModes = 11;
+struct Variant { int refill; KernelFn fn[3][kModes]; };  // [plain, stats, profile][MODE 0..10 of trace_kernel]
 #define RTGPU_VARIANT_ROW(S, R)                                                                         \
   {trace_kernel<S, R, 0>, trace_kernel<S, R, 1>, trace_kernel<S, R, 2>, trace_kernel<S, R, 3>, trace_kernel<S, R, 4>, \
-   trace_kernel<S, R, 5>, trace_kernel<S, R, 6>, trace_kernel<S, R, 7>, trace_kernel<S, R, 8>}
+   trace_kernel<S, R, 5>, trace_kernel<S, R, 6>, trace_kernel<S, R, 7>, trace_kernel<S, R, 8>, \
+   trace_kernel<S, R, 9>, trace_kernel<S, R, 10>}
 #define RTGPU_VARIANT(R) {R, {RTGPU_VARIANT_ROW(0, R), RTGPU_VARIANT_ROW(1, R), RTGPU_VARIANT_ROW(2, R)}}
 #ifndef RTGPU_REFILL_SMALL
 #define RTGPU_REFILL_SMALL 16
 #endif
 #ifndef RTGPU_REFILL_LARGE
-#define RTGPU_REFILL_LARGE 32
+#define RTGPU_REFILL_LARGE 40
 #endif
 const Variant kVariants[] = {RTGPU_VARIANT(0), RTGPU_VARIANT(RTGPU_REFILL_SMALL), RTGPU_VARIANT(RTGPU_REFILL_LARGE)};
 // Default refill threshold, by what bounds the scene: 16 where the whole tree
 // sits in LDS and the kernel is VALU-bound (an outer iteration is expensive, so leave
-// the traversal loop late); 32 where nodes come from memory and the time follows the
-// number of dependent steps a ray takes (so keep the lanes of a step together).
+// the traversal loop late); 40 where nodes come from memory and the time follows the
+// number of dependent steps a ray takes (so keep the lanes of a step together; measured 16 / 32 / 40 / 48 / 56).
 constexpr int kVariantSmallTree = 1, kVariantLargeTree = 2;
 
 bool hip_fail(rtgpu_ctx *ctx, hipError_t e, const char *what) {
@@ -2040,6 +2044,9 @@ int launch_frame(rtgpu_ctx *ctx, const rtgpu_camera *cam, const rtgpu_settings *
   // that may not use the context's overflow buffer, nor with RTGPU_WIDE_CACHE=0 (experiments).
   const bool wide_cache = wide && ctx->wide_cache && sc.may_allocate && kBlocksPerCU == 1;
   if (wide_cache) stack_fit = (uint32_t)((kLdsBytes - kWideCached * (int)sizeof(rtgpu_node4)) / (kBlock * sizeof(uint32_t)));
+  // experiment (RTGPU_DUAL=1): two work items per lane over a four-wide tree; the records take 32 KiB of the stacks' LDS
+  const bool wide_dual = wide && !wide_cache && ctx->dual && sc.may_allocate && kBlocksPerCU == 1;
+  if (wide_dual) stack_fit = (uint32_t)((kLdsBytes - 2 * 16 * kBlock) / (kBlock * sizeof(uint32_t)));
   if (stack_lds > stack_fit) stack_lds = stack_fit;
   P.stack_lds = stack_lds;
   P.stack_lds_only = (need <= stack_lds && !wide_cache) ? 1u : 0u;
@@ -2083,6 +2090,10 @@ int launch_frame(rtgpu_ctx *ctx, const rtgpu_camera *cam, const rtgpu_settings *
     if (mode == 2 || mode >= 7) { ctx->err = "internal: packed nodes on a tree that fits the LDS cache"; return 2; }
     mode += wide ? 5 : 3;
   }
+  if (wide_dual) {  // mode 5 (deeper stack entries in memory) or 6
+    mode = mode == 6 ? 9 : 10;
+    lds_bytes += 2u * 16u * kBlock;
+  }
   if (wide_cache) {  // mode == 5
     P.n_cached = (uint32_t)(ctx->host.n_nodes4 < (uint64_t)kWideCached ? ctx->host.n_nodes4 : (uint64_t)kWideCached);
     lds_bytes = stack_bytes + (size_t)kWideCached * sizeof(rtgpu_node4);
@@ -2096,7 +2107,7 @@ int launch_frame(rtgpu_ctx *ctx, const rtgpu_camera *cam, const rtgpu_settings *
     uint64_t cap = (uint64_t)ctx->num_cus * (uint64_t)ctx->blocks_per_cu[want_stats ? 1 : 0];
     unsigned grid = (unsigned)(want < cap ? want : cap);
     if ((size_t)grid * kBlock > ctx->ovf_threads) { ctx->err = "internal: grid exceeds the overflow stack"; return 2; }
-    const Variant &var = kVariants[ctx->variant >= 0 ? ctx->variant : (mode == 2 || mode >= 7 ? kVariantSmallTree : kVariantLargeTree)];
+    const Variant &var = kVariants[ctx->variant >= 0 ? ctx->variant : (mode == 2 || mode == 7 || mode == 8 ? kVariantSmallTree : kVariantLargeTree)];
     static_assert(RTGPU_NODE48_MIN_NODES > (unsigned)kSmallNodes, "a packed tree must not fit the LDS node cache");
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
     const int inst = (s->flags & RTGPU_FLAG_PROFILE) ? 2 : want_stats ? 1 : 0;

@@ -21,8 +21,8 @@ else
   for lib in rt_amd/librtgpu_d*.so; do
     [ -f "$lib" ] || continue
     echo "== $lib"
-    RTGPU_DUAL=1 RTGPU_LIB=$PWD/$lib timeout -k 10 120 python3 tools/gpu_perf.py c2 c4 2>&1 | grep -o "^c[0-9a-z]*:\|kernel ms.*Mrays/s" || exit 1
+    RTGPU_DUAL=1 RTGPU_LIB=$PWD/$lib timeout -k 10 120 python3 tools/gpu_perf.py ${CFGS:-c2 c4} 2>&1 | grep -o "^c[0-9a-z]*:\|trace_kernel.*Mrays/s" || exit 1
   done
   echo "== product (mode 7)"
-  timeout -k 10 120 python3 tools/gpu_perf.py c2 c4 2>&1 | grep -o "^c[0-9a-z]*:\|kernel ms.*Mrays/s"
+  timeout -k 10 120 python3 tools/gpu_perf.py ${CFGS:-c2 c4} 2>&1 | grep -o "^c[0-9a-z]*:\|trace_kernel.*Mrays/s"
 fi

@@ -58,7 +58,7 @@ def main():
               f"build+upload={t2-t1:.1f}s (bvh {fs.c.build_ms:.1f} ms) | {w}x{h}x{spp} rays={s['rays']} "
               f"nodes/ray={s['nodes']/s['rays']:.1f} tris/ray={s['tri_tests']/s['rays']:.1f} "
               f"sph/ray={s['sphere_tests']/s['rays']:.1f} B/ray={abytes/s['rays']:.0f} | "
-              f"kernel ms min={ms.min():.3f} med={np.median(ms):.3f} -> {s['rays']/np.median(ms)/1e3:.0f} Mrays/s, "
+              f"{ctx.kernel_name()} kernel ms min={ms.min():.3f} med={np.median(ms):.3f} -> {s['rays']/np.median(ms)/1e3:.0f} Mrays/s, "
               f"{abytes/np.median(ms)/1e6:.0f} GB/s algorithmic", flush=True)
     ctx.close()
 
