@@ -221,6 +221,26 @@ def test_random_scenes(ra, oracle, gpu_ctx, seed, n_sph, n_tri, mode):
         assert gpu_ctx.kernel_name().endswith(f",{mode}>"), gpu_ctx.kernel_name()
 
 
+@pytest.mark.parametrize("n_sph,n_mat,mode", [(512, 512, 7), (512, 513, 2), (400, 1, 7)])
+def test_whole_scene_in_lds_at_its_limits(ra, oracle, gpu_ctx, n_sph, n_mat, mode):
+    """Kernel mode 7 keeps tree, spheres, triangles and materials in LDS at fixed capacities (512 / 512 / 16 /
+    512): the last material slot and the last sphere slot are read from LDS, one more material sends the scene
+    back to mode 2."""
+    rng = np.random.default_rng(n_mat)
+    mats = [(int(i % 3), *rng.uniform(0.2, 1.0, 3).tolist(), 1.5 if i % 3 == 2 else float(rng.uniform(0, 0.5)) * (i % 3))
+            for i in range(n_mat)]
+    sph = [(*rng.uniform(-4, 4, 3).tolist(), float(rng.uniform(0.1, 0.5)), int((n_mat - 1 - i) % n_mat)) for i in range(n_sph)]
+    scene = make_scene(ra, spheres=sph, materials=mats)
+    cam = ra.look_at((0, 0, 9), (0, 0, 0), vfov=60.0, aspect=96 / 64)
+    st = ra.default_settings(96, 64, spp=3, max_depth=6, seed=n_mat)
+    (a, ia, sa), (b, ib, sb) = render_both(ra, oracle, gpu_ctx, scene, cam, st)
+    assert np.array_equal(ia, ib) and sa == sb
+    assert_bit_equal(a, b, f"{n_sph} spheres, {n_mat} materials")
+    assert gpu_ctx.kernel_name().endswith(f",{mode}>"), gpu_ctx.kernel_name()
+    assert len(np.unique(ia)) > 100          # many spheres seen, the last slots among them
+    assert (ia == 0).any() and (ia == n_sph - 1).any()
+
+
 def test_scene_replacement(ra, oracle, gpu_ctx):
     """A context renders whatever was uploaded last; going back gives the first frame again."""
     s0, cam0 = ra.Scene.builtin(0, aspect=2.0)
