@@ -196,12 +196,13 @@ __device__ __forceinline__ uint32_t pcg(uint32_t v) {
 struct Rng {
   uint32_t s;
   __device__ __forceinline__ void start(uint32_t key) { s = key * 747796405u + 2891336453u; }
-  __device__ __forceinline__ float u01() {
+  __device__ __forceinline__ uint32_t u24() {  // the top 24 bits of the next draw
     uint32_t w = ((s >> ((s >> 28) + 4u)) ^ s) * 277803737u;
     uint32_t h = (w >> 22) ^ w;
     s += 0xDE500ECDu;  // 747796405 * 0x9E3779B9 mod 2^32
-    return (float)(h >> 8) * 0x1p-24f;
+    return h >> 8;
   }
+  __device__ __forceinline__ float u01() { return (float)u24() * 0x1p-24f; }
 };
 static_assert((uint32_t)(747796405ull * 0x9E3779B9ull) == 0xDE500ECDu, "step of the carried pcg state");
 
@@ -209,18 +210,31 @@ __device__ __forceinline__ float clamp_dir(float d) {
   return __builtin_fabsf(d) < 1e-30f ? __builtin_copysignf(1e-30f, d) : d;
 }
 
+// Uniform direction on the unit sphere from exactly two draws (oracle/rt_oracle.c random_unit_vector, the same
+// single f32 operations in the same order): z on a 24-bit grid, azimuth = quadrant + Taylor sine / cosine of an
+// angle within [-pi/4, pi/4) in Horner form.  No rejection loop: a loop runs as long as the unluckiest of the
+// wave's 64 lanes (3.3 rounds of ~42 instructions on average for the two-dimensional rejection used before).
 __device__ __forceinline__ V3 random_unit_vector(Rng &rng) {
-  float a = 0.0f, b = 0.0f, s = 0.0f;
-  bool found = false;
-#pragma unroll 1
-  for (int i = 0; i < 8 && !found; i++) {
-    float ta = rng.u01() * 2.0f - 1.0f;
-    float tb = rng.u01() * 2.0f - 1.0f;
-    float ts = ta * ta + tb * tb;
-    if (ts < 1.0f) { a = ta; b = tb; s = ts; found = true; }
-  }
-  float f = 2.0f * sqrt_fast(1.0f - s);  // 1 - s is 1 or a multiple of 2^-24 in (0, 1)
-  return mk(a * f, b * f, 1.0f - 2.0f * s);
+  const uint32_t k1 = rng.u24(), k2 = rng.u24();
+  const float t = (float)k1 * 0x1p-23f;
+  const float z = 1.0f - t;
+  const float rad = sqrt_fast(t * (2.0f - t));  // 0 or >= 2^-23: inside sqrt_fast's verified range
+  const uint32_t q = k2 >> 22;
+  const float f = (float)(k2 & 0x3FFFFFu) * 0x1p-22f - 0.5f;
+  const float x = f * 1.57079637f;
+  const float x2 = x * x;
+  float ps = __builtin_fmaf(x2, 2.75573192e-6f, -1.98412701e-4f);
+  ps = __builtin_fmaf(x2, ps, 8.33333377e-3f);
+  ps = __builtin_fmaf(x2, ps, -1.66666672e-1f);
+  const float sn = __builtin_fmaf(x * x2, ps, x);
+  float pc = __builtin_fmaf(x2, 2.48015876e-5f, -1.38888892e-3f);
+  pc = __builtin_fmaf(x2, pc, 4.16666679e-2f);
+  pc = __builtin_fmaf(x2, pc, -0.5f);
+  const float cs = __builtin_fmaf(x2, pc, 1.0f);
+  float ex = (q & 1u) ? sn : cs, ey = (q & 1u) ? cs : sn;
+  ex = __uint_as_float(__float_as_uint(ex) ^ (((q + 1u) & 2u) << 30));
+  ey = __uint_as_float(__float_as_uint(ey) ^ ((q & 2u) << 30));
+  return mk(rad * ex, rad * ey, z);
 }
 
 __device__ __forceinline__ V3 reflect(V3 d, V3 n) {
