@@ -1418,7 +1418,7 @@ namespace {
 
 // Kernel variants: {refill threshold} x {plain, instrumented}.  One source, one
 // code path; the threshold only changes WHEN finished lanes are refilled, never
-// what a path computes.  RTGPU_REFILL (0/16/40) selects it for experiments.
+// what a path computes.  RTGPU_REFILL (0/20/40) selects it for experiments.
 using KernelFn = void (*)(const KParams);
 constexpr int kModes = 11;
 struct Variant { int refill; KernelFn fn[3][kModes]; };  // [plain, stats, profile][MODE 0..10 of trace_kernel]
@@ -1428,13 +1428,13 @@ struct Variant { int refill; KernelFn fn[3][kModes]; };  // [plain, stats, profi
    trace_kernel<S, R, 9>, trace_kernel<S, R, 10>}
 #define RTGPU_VARIANT(R) {R, {RTGPU_VARIANT_ROW(0, R), RTGPU_VARIANT_ROW(1, R), RTGPU_VARIANT_ROW(2, R)}}
 #ifndef RTGPU_REFILL_SMALL
-#define RTGPU_REFILL_SMALL 16
+#define RTGPU_REFILL_SMALL 20
 #endif
 #ifndef RTGPU_REFILL_LARGE
 #define RTGPU_REFILL_LARGE 40
 #endif
 const Variant kVariants[] = {RTGPU_VARIANT(0), RTGPU_VARIANT(RTGPU_REFILL_SMALL), RTGPU_VARIANT(RTGPU_REFILL_LARGE)};
-// Default refill threshold, by what bounds the scene: 16 where the whole tree
+// Default refill threshold, by what bounds the scene: 20 where the whole tree
 // sits in LDS and the kernel is VALU-bound (an outer iteration is expensive, so leave
 // the traversal loop late); 40 where nodes come from memory and the time follows the
 // number of dependent steps a ray takes (so keep the lanes of a step together; measured 16 / 32 / 40 / 48 / 56).
