@@ -321,7 +321,11 @@ const char *rtgpu_last_kernel_name(const rtgpu_ctx *ctx);
  * SIMD lane utilisation of each section; [16..20] = shader-clock cycles summed
  * over waves spent in {shading, work-item bookkeeping, camera rays, traversal
  * set-up, traversal}; [21], [22] = the node-phase and leaf-phase cycles inside the
- * traversal figure; [23..31] zero.  Synchronises the device. */
+ * traversal figure; [23..25] = lanes in node steps, of them served from the LDS copy of the
+ * top of a four-wide tree, steps on the slow stack path (RTGPU_WIDE_CACHE=1 experiment);
+ * [26], [27] = lanes that still had a ray in traversal, summed over the node steps / leaf
+ * steps of every wave; [28], [29] = slot exchanges per wave and lanes that took part
+ * (RTGPU_DUAL=1 experiment); [30], [31] zero.  Synchronises the device. */
 int  rtgpu_profile_counters(rtgpu_ctx *ctx, uint64_t out[32]);
 
 /* accum (float4 sums) -> 0xRRGGBBAA, gamma 2, like RTIOW's write_color.
