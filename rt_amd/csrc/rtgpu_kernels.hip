@@ -410,7 +410,10 @@ void trace_kernel(const KParams P) {
 #else
   constexpr bool KEEP_N = !SMALL;
 #endif
-  constexpr int TRIS = SMALL ? 1 : kTriStep;  // triangles per leaf step (two in the LDS mode measured C2 1.4 % slower)
+#ifndef RTGPU_TINY_TRIS
+#define RTGPU_TINY_TRIS 1
+#endif
+  constexpr int TRIS = TINY ? RTGPU_TINY_TRIS : SMALL ? 1 : kTriStep;  // triangles per leaf step (two in the LDS mode measured C2 1.4 % slower)
   // LDS: [traversal stacks: stack_lds x kBlock u32][node cache: 4 planes x n_cached float4]
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   uint32_t *const lds_stack = smem;
@@ -1129,8 +1132,9 @@ void trace_kernel(const KParams P) {
 #pragma unroll
             for (int k = 0; k < TRIS; k++) {
               // a lane with fewer triangles left re-reads its last one (never past the array)
-              if (TINY) {  // TRIS == 1
-                const f4 a = tri_cache[i3], b = tri_cache[i3 + 1u], c = tri_cache[i3 + 2u];
+              if (TINY) {
+                const uint32_t j3 = i3 + 3u * ((uint32_t)k < more ? (uint32_t)k : more);
+                const f4 a = tri_cache[j3], b = tri_cache[j3 + 1u], c = tri_cache[j3 + 2u];
                 rec[k][0] = make_float4(a.x, a.y, a.z, a.w); rec[k][1] = make_float4(b.x, b.y, b.z, b.w);
                 rec[k][2] = make_float4(c.x, c.y, c.z, c.w);
               } else {
