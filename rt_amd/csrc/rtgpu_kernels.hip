@@ -76,12 +76,14 @@ constexpr int      kSmallNodes = RTGPU_SMALL_NODES;
 #define RTGPU_DUAL_REFILL 16
 #endif
 // MODE 7 of the trace kernel: a scene small enough to sit in LDS WHOLE - tree (planes kTinyNodes apart), leaf-ordered
-// spheres and their {id, material} pairs, triangles, materials - at compile-time distances from the node planes, so
-// that every read of the scene is a ds_read with an immediate offset and the kernel touches memory only for the
-// work queue and the pixels.  Offsets in 16-byte units from the first plane; the last array ends below 64 KiB.
-constexpr int      kTinyNodes = 512, kTinySphs = 512, kTinyTris = 16, kTinyMats = 512;
-constexpr int      kTinySphAt = 4 * kTinyNodes, kTinyTriAt = kTinySphAt + kTinySphs, kTinyMatAt = kTinyTriAt + 3 * kTinyTris,
-                   kTinyMetaAt = kTinyMatAt + 2 * kTinyMats, kTinyEnd = kTinyMetaAt + kTinySphs / 2;
+// spheres, triangles, and per PRIMITIVE what shading needs: the triangle's unit normal and id, the sphere's id and
+// 1/r, and a copy of the primitive's material - at compile-time distances from the node planes, so that every read
+// of the scene is a ds_read with an immediate offset, no read depends on another, and the kernel touches memory only
+// for the work queue and the pixels.  Offsets in 16-byte units from the first plane; the last array ends below 64 KiB.
+constexpr int      kTinyNodes = 512, kTinySphs = 496, kTinyTris = 16;
+constexpr int      kTinySphAt = 4 * kTinyNodes, kTinyTriAt = kTinySphAt + kTinySphs, kTinyTriNAt = kTinyTriAt + 3 * kTinyTris,
+                   kTinySphMatAt = kTinyTriNAt + kTinyTris, kTinyTriMatAt = kTinySphMatAt + 2 * kTinySphs,
+                   kTinyMetaAt = kTinyTriMatAt + 2 * kTinyTris, kTinyEnd = kTinyMetaAt + kTinySphs / 2;
 static_assert(kTinyEnd * 16 <= 65536, "MODE 7: every array within reach of a 16-bit ds_read offset");
 // MODE 5 of the trace kernel: the first kWideCached four-wide nodes (the top of the tree: both
 // collapses number it breadth first) live in LDS as six 16-byte planes this many nodes apart
@@ -111,7 +113,7 @@ struct KParams {
   uint32_t stack_lds, stack_lds_only;
   uint32_t n_cached;  // nodes [0, n_cached) are read from the LDS copy
   uint32_t sph_cached; // MODE 2, 7: > 0 = the leaf-ordered spheres (this many: all of them) sit in LDS behind the node planes
-  uint32_t tiny_tris, tiny_mats;  // MODE 7: triangles and materials to copy to LDS (all of them)
+  uint32_t tiny_tris;  // MODE 7: triangles to copy to LDS (all of them)
   uint32_t tiles_small;  // all tile indices < 2^22: the float tile-row estimate is usable
   float inv_tiles_x;
   // chunked frame sums (rtgpu_settings.chunk_samples): n_chunks work items per pixel; with
@@ -510,10 +512,12 @@ void trace_kernel(const KParams P) {
       f4 w = {v.x, v.y, v.z, v.w};
       sph_cache[i] = w;
     }
-  // MODE 7: and the triangles, the materials and the spheres' {id, material} pairs
+  // MODE 7: and the triangles, and per primitive what shading reads (computed here once per block with the
+  // operations shading would use: the same bits)
   typedef uint32_t u2 __attribute__((ext_vector_type(2)));
   typedef __attribute__((address_space(3))) u2 lds_u2;
-  lds_f4 *const tri_cache = node_cache + kTinyTriAt, *const mat_cache = node_cache + kTinyMatAt;
+  lds_f4 *const tri_cache = node_cache + kTinyTriAt, *const trin_cache = node_cache + kTinyTriNAt,
+         *const sphmat_cache = node_cache + kTinySphMatAt, *const trimat_cache = node_cache + kTinyTriMatAt;
   lds_u2 *const meta_cache = (lds_u2 *)(node_cache + kTinyMetaAt);
   if (TINY) {
     for (uint32_t i = tid; i < P.tiny_tris * 3u; i += kBlock) {
@@ -521,15 +525,25 @@ void trace_kernel(const KParams P) {
       f4 w = {v.x, v.y, v.z, v.w};
       tri_cache[i] = w;
     }
-    for (uint32_t i = tid; i < P.tiny_mats * 2u; i += kBlock) {
-      float4 v = P.mats[i];
-      f4 w = {v.x, v.y, v.z, v.w};
-      mat_cache[i] = w;
+    for (uint32_t i = tid; i < P.tiny_tris; i += kBlock) {
+      const float4 t0 = P.tris[3u * i], t1 = P.tris[3u * i + 1u], t2 = P.tris[3u * i + 2u];
+      const V3 n = normalize(cross(mk(t1.x, t1.y, t1.z), mk(t2.x, t2.y, t2.z)));
+      const f4 w = {n.x, n.y, n.z, t0.w};  // unit normal | id
+      trin_cache[i] = w;
+      const uint32_t m = __float_as_uint(t1.w);
+      const float4 a = P.mats[2u * m], b = P.mats[2u * m + 1u];
+      const f4 wa = {a.x, a.y, a.z, a.w}, wb = {b.x, b.y, b.z, b.w};
+      trimat_cache[2u * i] = wa;
+      trimat_cache[2u * i + 1u] = wb;
     }
     for (uint32_t i = tid; i < P.sph_cached; i += kBlock) {
       const uint2 v = P.sph_meta[i];
-      const u2 w = {v.x, v.y};
+      const u2 w = {v.x, __float_as_uint(rcp_exact(P.sphs[i].w))};  // id | 1/r
       meta_cache[i] = w;
+      const float4 a = P.mats[2u * v.y], b = P.mats[2u * v.y + 1u];
+      const f4 wa = {a.x, a.y, a.z, a.w}, wb = {b.x, b.y, b.z, b.w};
+      sphmat_cache[2u * i] = wa;
+      sphmat_cache[2u * i + 1u] = wb;
     }
   }
   if (HYBRID)  // quarter j of four-wide node k -> plane j, slot k
@@ -619,31 +633,30 @@ void trace_kernel(const KParams P) {
           float4 s;
           if (sph_in_lds) { const f4 w = sph_cache[hit_slot]; s = make_float4(w.x, w.y, w.z, w.w); }
           else s = P.sphs[hit_slot];
-          uint2 meta;
-          if (TINY) { const u2 w = meta_cache[hit_slot]; meta = make_uint2(w.x, w.y); }
-          else meta = P.sph_meta[hit_slot];
-          float inv_r = rcp_exact(s.w);
-          n = (p - mk(s.x, s.y, s.z)) * inv_r;
-          prim = meta.x;
           if (TINY) {
-            const f4 a = mat_cache[meta.y * 2u], b = mat_cache[meta.y * 2u + 1u];
+            const u2 w = meta_cache[hit_slot];
+            const f4 a = sphmat_cache[hit_slot * 2u], b = sphmat_cache[hit_slot * 2u + 1u];
+            n = (p - mk(s.x, s.y, s.z)) * __uint_as_float(w.y);
+            prim = w.x;
             m0 = make_float4(a.x, a.y, a.z, a.w); m1 = make_float4(b.x, b.y, b.z, b.w);
           } else {
+            const uint2 meta = P.sph_meta[hit_slot];
+            float inv_r = rcp_exact(s.w);
+            n = (p - mk(s.x, s.y, s.z)) * inv_r;
+            prim = meta.x;
             m0 = P.mats[meta.y * 2u]; m1 = P.mats[meta.y * 2u + 1u];
           }
         } else {
           // the material index came with the hit: its two loads go out with the triangle's
-          float4 t0, t1, t2;
           if (TINY) {
-            const f4 a = tri_cache[hit_slot * 3u], b = tri_cache[hit_slot * 3u + 1u], c = tri_cache[hit_slot * 3u + 2u];
-            const f4 d = mat_cache[hit_mat * 2u], e = mat_cache[hit_mat * 2u + 1u];
-            t0 = make_float4(a.x, a.y, a.z, a.w); t1 = make_float4(b.x, b.y, b.z, b.w); t2 = make_float4(c.x, c.y, c.z, c.w);
+            const f4 w = trin_cache[hit_slot];
+            const f4 d = trimat_cache[hit_slot * 2u], e = trimat_cache[hit_slot * 2u + 1u];
+            n = mk(w.x, w.y, w.z);
+            prim = __float_as_uint(w.w);
             m0 = make_float4(d.x, d.y, d.z, d.w); m1 = make_float4(e.x, e.y, e.z, e.w);
-            n = normalize(cross(mk(t1.x, t1.y, t1.z), mk(t2.x, t2.y, t2.z)));
-            prim = __float_as_uint(t0.w);
           } else if (!KEEP_N) {
             const float4 *tp = P.tris + (size_t)hit_slot * (sizeof(rtgpu_tri) / 16);
-            t0 = tp[0]; t1 = tp[1]; t2 = tp[2];
+            const float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
             m0 = P.mats[hit_mat * 2u]; m1 = P.mats[hit_mat * 2u + 1u];
             n = normalize(cross(mk(t1.x, t1.y, t1.z), mk(t2.x, t2.y, t2.z)));
             prim = __float_as_uint(t0.w);
@@ -2100,12 +2113,10 @@ int launch_frame(rtgpu_ctx *ctx, const rtgpu_camera *cam, const rtgpu_settings *
     }
     // a scene that fits LDS whole (S0 does): MODE 7
     if (!ctx->no_sphere_cache && !ctx->no_tiny && kBlocksPerCU == 1 && ctx->host.n_nodes <= (uint64_t)kTinyNodes &&
-        ctx->host.n_spheres <= (uint64_t)kTinySphs && ctx->host.n_tris <= (uint64_t)kTinyTris &&
-        ctx->host.n_materials <= (uint64_t)kTinyMats && stack_bytes + (size_t)kTinyEnd * 16 <= (size_t)kLdsBytes) {
+        ctx->host.n_spheres <= (uint64_t)kTinySphs && ctx->host.n_tris <= (uint64_t)kTinyTris && stack_bytes + (size_t)kTinyEnd * 16 <= (size_t)kLdsBytes) {
       mode = 7;
       P.sph_cached = (uint32_t)ctx->host.n_spheres;
       P.tiny_tris = (uint32_t)ctx->host.n_tris;
-      P.tiny_mats = (uint32_t)ctx->host.n_materials;
       lds_bytes = stack_bytes + (size_t)kTinyEnd * 16;
       if (ctx->dual && lds_bytes + 2u * 16u * kBlock <= (size_t)kLdsBytes) {  // experiment: two work items per lane
         mode = 8;
