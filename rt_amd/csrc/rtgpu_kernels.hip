@@ -509,7 +509,7 @@ void trace_kernel(const KParams P) {
   if (sph_in_lds)
     for (uint32_t i = tid; i < P.sph_cached; i += kBlock) {
       float4 v = P.sphs[i];
-      f4 w = {v.x, v.y, v.z, v.w};
+      f4 w = {v.x, v.y, v.z, TINY ? v.w * v.w : v.w};  // MODE 7: centre | r^2 (shading has 1/r in its own record)
       sph_cache[i] = w;
     }
   // MODE 7: and the triangles, and per primitive what shading reads (computed here once per block with the
@@ -840,7 +840,7 @@ void trace_kernel(const KParams P) {
         px = g_px + wx;
         py = g_py + wy;
         pixel_valid = px < P.width && py < P.height;
-        out_index = g_out + wy * g_row + wx;
+        out_index = g_out + __umul24(wy, g_row) + wx;  // both below 2^24 (width <= 65536): v_mad_u32_u24 is full rate
         chunk = g_chunk;
         have_pixel = true;
         sample = pixel_valid ? g_sample : g_sample_end;  // out-of-image pixel: nothing to trace
@@ -856,7 +856,7 @@ void trace_kernel(const KParams P) {
     if (!alive && !done && have_pixel && sample < sample_end) {
       // ---- camera ray (row a1) ----
       if (STATS == 2) wave_tick(lane, w_gen);
-      rng.start(pcg((P.sample_offset + sample) ^ pcg((py * P.width + px) ^ seed_hash)));
+      rng.start(pcg((P.sample_offset + sample) ^ pcg((__umul24(py, P.width) + px) ^ seed_hash)));
       float jx = rng.u01(), jy = rng.u01();
       float sx = ((float)px + jx) * P.inv_w;
       float sy = ((float)py + jy) * P.inv_h;
@@ -1128,7 +1128,7 @@ void trace_kernel(const KParams P) {
             if (STATS == 2) wave_tick(lane, w_sph);
             V3 oc = ro - mk(s.x, s.y, s.z);
             float hb = dot(oc, rd);
-            float cc = dot(oc, oc) - s.w * s.w;
+            float cc = dot(oc, oc) - (TINY ? s.w : s.w * s.w);
             float disc = hb * hb - cc;
             float sq = sqrt_exact(disc);  // NaN for a negative discriminant: fails every test below
             float t = -hb - sq;
