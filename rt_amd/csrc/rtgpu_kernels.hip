@@ -63,6 +63,9 @@ constexpr uint32_t kDone       = 0xFFFFFFFFu;  // == RTGPU_REF_EMPTY, has the le
 constexpr int      kSmallNodes = RTGPU_SMALL_NODES;
 // MODE 8 (two work items per lane, an experiment): a shading pass for the second slots runs while this many lanes
 // hold a result there; lanes exchange their slots mid-round from this many up; the round ends below this many
+#ifndef RTGPU_NODE_UNROLL  // node steps per vote on the scenes in LDS: the vote is 4 of a step's ~45 instructions (1 / 2 / 3 / 4: C4 206.8 / 204.4 / 207.0 / 209.1 ms)
+#define RTGPU_NODE_UNROLL 2
+#endif
 #ifndef RTGPU_PRIO_SMALL
 #define RTGPU_PRIO_SMALL 1
 #endif
@@ -945,6 +948,8 @@ void trace_kernel(const KParams P) {
       const int node_quorum = (2 * n_trav + 2) / 3, leaf_quorum = n_trav / 3 + 1;
       if (n_node >= node_quorum) {
         do {
+#pragma unroll
+          for (int unroll_ = 0; unroll_ < (SMALL ? RTGPU_NODE_UNROLL : 1); unroll_++) {
           if (STATS == 2) { const int n_ = wave_count((int)cur != -1); if (lane == 0) t_node += (unsigned long long)n_; }
           if (WIDE && (int)cur >= 0) {
             if (STATS == 2) wave_tick(lane, w_node);
@@ -1106,6 +1111,7 @@ void trace_kernel(const KParams P) {
             uint32_t near_c = (h0 && !(h1 && swap)) ? c0 : c1;
             uint32_t far_c = swap ? c0 : c1;
             cur = stk.step(h0 && h1, !(h0 || h1), near_c, far_c, top);
+          }
           }
           n_node = wave_count((int)cur >= 0);
         } while (n_node >= node_quorum);
