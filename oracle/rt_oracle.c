@@ -466,7 +466,9 @@ static inline int scatter(uint32_t type, float param, v3 d, v3 n, rng_t *rng, v3
     if (fabsf(sd.x) < 1e-8f && fabsf(sd.y) < 1e-8f && fabsf(sd.z) < 1e-8f) sd = n;
     nd = v3_normalize(sd);
   } else if (type == RTGPU_MAT_METAL) {
-    v3 rf = v3_normalize(reflect(d, n));
+    /* d and n are unit vectors, so reflect(d, n) is one to rounding (RTIOW normalises here because its ray
+     * directions are not unit; the next segment's direction is normalised below in any case) */
+    v3 rf = reflect(d, n);
     if (param > 0.0f) {
       v3 ruv = random_unit_vector(rng);
       rf = v3_add(rf, v3_scale(ruv, param));

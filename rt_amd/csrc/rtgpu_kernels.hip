@@ -692,7 +692,7 @@ void trace_kernel(const KParams P) {
           if (__builtin_fabsf(sd.x) < 1e-8f && __builtin_fabsf(sd.y) < 1e-8f && __builtin_fabsf(sd.z) < 1e-8f)
             sd = n;
         } else if (is_metal) {
-          sd = normalize(reflect(rd, n));
+          sd = reflect(rd, n);  // unit to rounding: rd and n are
           if (param > 0.0f) sd = sd + ruv * param;
           absorbed = !(dot(sd, n) > 0.0f);
         } else if (mtype == RTGPU_MAT_EMISSIVE) {
