@@ -403,10 +403,12 @@ __device__ __forceinline__ void wave_tick(unsigned lane, unsigned long long &c) 
 // 5 and 6: as 0 and 1 over the four-wide packed nodes (rtgpu_node4): a step tests up to four
 // children with six loads, and a ray takes about half as many dependent steps.  6 keeps the whole
 // stack in LDS; 5 gives the stack what is left beside an LDS copy of the first kWideCached nodes
-// (six planes, kWideCached nodes apart) and sends deeper stack entries to global memory: on
-// these trees the kernel is bound by the vector memory pipeline (TA / TCP / TD ~ 90 % busy, one
-// tag lookup per lane and 16-byte load), and every node step served from LDS is six fewer loads
-// per lane for it.
+// (six planes, kWideCached nodes apart) and sends deeper stack entries to global memory (the LDS
+// copy measured slower and is off unless RTGPU_WIDE_CACHE=1; the hybrid stack is what trees with a
+// stack bound above 40 entries run on).  7: as 2 for a scene that fits LDS WHOLE (kTiny* above):
+// spheres, triangles and per-primitive shading records behind the tree; S0 runs this.
+// 8, 9, 10: modes 7, 6, 5 with TWO work items per lane (RTGPU_DUAL=1): the measured-negative
+// experiment of row N1, profiles/r02/experiments.txt H and J.
 template <int STATS, int REFILL, int MODE>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RTGPU_WAVES_PER_EU, RTGPU_WAVES_PER_EU)))
 void trace_kernel(const KParams P) {
