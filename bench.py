@@ -323,7 +323,17 @@ def main():
     if rank == 0:
         k_ms = sum(kernel_ms) / len(kernel_ms)
         n_px_rank = counts["paths"] // spp
-        pmc, ub = committed_pmc(config, W, H, spp_arg, depth) if world == 1 else (None, committed_pmc("", 0, 0, 0, 0)[1])
+        pmc, ub = committed_pmc(config, W, H, spp_arg, depth)
+        if world > 1 and pmc and config == "c4":
+            # rank 0's launch: its 1/N share of the tiles of the frame whose single-GPU launch the PMC passes measured
+            # (the traffic is the chunk planes and sums of the rank's own pixels; the scene is read once per block)
+            pmc = dict(pmc)
+            for k in ("traffic_bytes_per_launch", "valu_insts_per_launch", "fetch_size_kib", "write_size_kib"):
+                if pmc.get(k) is not None:
+                    pmc[k] = pmc[k] / world
+            pmc["source"] = f"1/{world} of: " + pmc.get("source", "")
+        elif world > 1:
+            pmc = None
         ms_step = dt / steps * 1e3
         name = "C2" if config == "c2" else "C4"
         out = {
