@@ -93,6 +93,7 @@ static_assert(kTinyEnd * 16 <= 65536, "MODE 7: every array within reach of a 16-
 // (the last plane's immediate ds_read offset, 5 * 16 * kWideCached, has to fit in 16 bits),
 // and the traversal stacks get the rest of the LDS, deeper entries going to global memory
 constexpr int      kWideCached = 768;
+constexpr int      kLdsMats    = 64;   // trees in memory: material tables up to this size are copied to LDS (2 KiB)
 constexpr unsigned kChunk      = 64;   // work items drawn per queue atomic (one 8x8 pixel block)
 constexpr float    kTMax       = 3.402823466e+38f;  // FLT_MAX: initial closest-hit distance
 
@@ -117,6 +118,7 @@ struct KParams {
   uint32_t n_cached;  // nodes [0, n_cached) are read from the LDS copy
   uint32_t sph_cached; // MODE 2, 7: > 0 = the leaf-ordered spheres (this many: all of them) sit in LDS behind the node planes
   uint32_t tiny_tris;  // MODE 7: triangles to copy to LDS (all of them)
+  uint32_t mats_cached;  // modes 0, 1, 3-6: > 0 = the material table (this many entries: all) sits in LDS behind the stacks
   uint32_t tiles_small;  // all tile indices < 2^22: the float tile-row estimate is usable
   float inv_tiles_x;
   // chunked frame sums (rtgpu_settings.chunk_samples): n_chunks work items per pixel; with
@@ -551,6 +553,24 @@ void trace_kernel(const KParams P) {
       sphmat_cache[2u * i + 1u] = wb;
     }
   }
+  // Trees in memory: a small material table (<= kLdsMats entries) behind the stacks, so that the shading pass waits
+  // for no vector load at all (the triangle's normal and id are in registers, KEEP_N)
+  lds_f4 *const mats_lds = node_cache + ((HYBRID && n_cached) ? 6 * kWideCached : 0);
+  const bool mats_in_lds = !SMALL && !DUAL && P.mats_cached != 0u;
+  if (mats_in_lds)
+    for (uint32_t i = tid; i < P.mats_cached * 2u; i += kBlock) {
+      float4 v = P.mats[i];
+      f4 w = {v.x, v.y, v.z, v.w};
+      mats_lds[i] = w;
+    }
+  auto load_mat = [&](uint32_t m, float4 &m0, float4 &m1) __attribute__((always_inline)) {
+    if (mats_in_lds) {
+      const f4 a = mats_lds[m * 2u], b = mats_lds[m * 2u + 1u];
+      m0 = make_float4(a.x, a.y, a.z, a.w); m1 = make_float4(b.x, b.y, b.z, b.w);
+    } else {
+      m0 = P.mats[m * 2u]; m1 = P.mats[m * 2u + 1u];
+    }
+  };
   if (HYBRID)  // quarter j of four-wide node k -> plane j, slot k
     for (uint32_t i = tid; i < n_cached * 6u; i += kBlock) {
       float4 v = P.nodes[i];
@@ -649,7 +669,7 @@ void trace_kernel(const KParams P) {
             float inv_r = rcp_exact(s.w);
             n = (p - mk(s.x, s.y, s.z)) * inv_r;
             prim = meta.x;
-            m0 = P.mats[meta.y * 2u]; m1 = P.mats[meta.y * 2u + 1u];
+            load_mat(meta.y, m0, m1);
           }
         } else {
           // the material index came with the hit: its two loads go out with the triangle's
@@ -662,11 +682,11 @@ void trace_kernel(const KParams P) {
           } else if (!KEEP_N) {
             const float4 *tp = P.tris + (size_t)hit_slot * (sizeof(rtgpu_tri) / 16);
             const float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
-            m0 = P.mats[hit_mat * 2u]; m1 = P.mats[hit_mat * 2u + 1u];
+            load_mat(hit_mat, m0, m1);
             n = normalize(cross(mk(t1.x, t1.y, t1.z), mk(t2.x, t2.y, t2.z)));
             prim = __float_as_uint(t0.w);
           } else {
-            m0 = P.mats[hit_mat * 2u]; m1 = P.mats[hit_mat * 2u + 1u];
+            load_mat(hit_mat, m0, m1);
             n = normalize(hit_n);
             prim = hit_prim;
           }
@@ -1420,6 +1440,7 @@ struct rtgpu_ctx {
   int stack_lds = kStackLds;    // cap on LDS stack entries (RTGPU_STACK_LDS shrinks it for tests)
   bool no_node_cache = false;   // RTGPU_NO_NODE_CACHE=1: every node through the vector L1 (experiments)
   bool dual = false;            // RTGPU_DUAL=1: MODE 8 instead of 7 (experiment)
+  bool no_mats_cache = false;   // RTGPU_NO_MATS_CACHE=1: trees in memory read materials through L1 (experiments)
   bool no_tiny = false;         // RTGPU_NO_TINY=1: a scene that fits LDS whole still runs MODE 2 (experiments)
   bool no_sphere_cache = false; // RTGPU_NO_SPHERE_CACHE=1: MODE 2 reads spheres through L1 as before (experiments)
   bool wide_cache = false;      // RTGPU_WIDE_CACHE=1: four-wide trees with an LDS copy of their top (measured slower)
@@ -1592,6 +1613,7 @@ extern "C" int rtgpu_create(rtgpu_ctx **out, int device_index) {
   if (const char *env = std::getenv("RTGPU_NO_SPHERE_CACHE")) ctx->no_sphere_cache = std::atoi(env) != 0;
   if (const char *env = std::getenv("RTGPU_NO_TINY")) ctx->no_tiny = std::atoi(env) != 0;
   if (const char *env = std::getenv("RTGPU_DUAL")) ctx->dual = std::atoi(env) != 0;
+  if (const char *env = std::getenv("RTGPU_NO_MATS_CACHE")) ctx->no_mats_cache = std::atoi(env) != 0;
   if (const char *env = std::getenv("RTGPU_STACK_LDS")) {
     int want = std::atoi(env);
     if (want >= 2 && want <= kStackLds) ctx->stack_lds = want;
@@ -2143,6 +2165,19 @@ int launch_frame(rtgpu_ctx *ctx, const rtgpu_camera *cam, const rtgpu_settings *
   if (wide_cache) {  // mode == 5
     P.n_cached = (uint32_t)(ctx->host.n_nodes4 < (uint64_t)kWideCached ? ctx->host.n_nodes4 : (uint64_t)kWideCached);
     lds_bytes = stack_bytes + (size_t)kWideCached * sizeof(rtgpu_node4);
+  }
+  if (mode != 2 && mode != 7 && mode != 8 && !wide_dual && !ctx->no_mats_cache && ctx->host.n_materials > 0 &&
+      ctx->host.n_materials <= (uint64_t)kLdsMats && kBlocksPerCU == 1) {
+    const size_t mb = (size_t)ctx->host.n_materials * sizeof(rtgpu_material);
+    if (lds_bytes + mb > (size_t)kLdsBytes && !P.stack_lds_only && sc.may_allocate && P.stack_lds > 8u) {
+      // an overflow-capable stack gives up one LDS entry for the table
+      P.stack_lds -= 1u;
+      lds_bytes -= (size_t)kBlock * sizeof(uint32_t);
+    }
+    if (lds_bytes + mb <= (size_t)kLdsBytes) {
+      P.mats_cached = (uint32_t)ctx->host.n_materials;
+      lds_bytes += mb;
+    }
   }
 
   bool want_stats = (s->flags & (RTGPU_FLAG_STATS | RTGPU_FLAG_PROFILE)) != 0;

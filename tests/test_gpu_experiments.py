@@ -17,6 +17,7 @@ CASES = [
     ({"RTGPU_DUAL": "1", "RTGPU_STACK_LDS": "14"}, (8, 10)),        # ... with the mesh's stack entries beyond 14 in memory
     ({"RTGPU_WIDE_CACHE": "1"}, (7, 5)),                            # experiment A: top of the four-wide tree in LDS
     ({"RTGPU_REFILL": "0"}, (7, 6)),                                # plain while-while traversal rounds
+    ({"RTGPU_NO_MATS_CACHE": "1"}, (7, 6)),                         # trees in memory: materials through L1, not LDS
 ]
 
 
