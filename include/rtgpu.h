@@ -367,6 +367,11 @@ int  rtgpu_group_create(rtgpu_group **out, const int *devices, int n_devices);
 void rtgpu_group_destroy(rtgpu_group *g);
 const char *rtgpu_group_last_error(const rtgpu_group *g);   /* g may be NULL: last create error */
 int  rtgpu_group_size(const rtgpu_group *g);
+/* Ranks of the RCCL communicator the group exchanges tiles over: n_devices for distinct devices,
+ * 0 when a device is listed twice (rehearsal: device copies, no RCCL), 1 for a one-device group
+ * created with RTGPU_GROUP_SELF_RCCL=1 (its buffer then goes through a grouped ncclSend / ncclRecv to
+ * itself: the part of the wire a one-GPU box can run), else 0 for a one-device group. */
+int  rtgpu_group_comm_ranks(const rtgpu_group *g);
 /* builder: 0 = binned SAH on the host (built once, uploaded to every GPU), 1 = LBVH, built by
  * every GPU for itself from the uploaded primitives (same bytes on every GPU). */
 int  rtgpu_group_upload_scene(rtgpu_group *g, const rtgpu_scene_desc *scene, int builder);
@@ -380,7 +385,11 @@ int  rtgpu_group_render_end(rtgpu_group *g, float *accum_rgba, uint32_t *rgba8, 
 /* _begin + _end */
 int  rtgpu_group_render(rtgpu_group *g, const rtgpu_camera *cam, const rtgpu_settings *s,
                         float *accum_rgba, uint32_t *rgba8, rtgpu_stats *stats);
-/* Trace-kernel time of the last ended frame on GPU `index` of the list (ms). */
+/* After a failure in the exchange step (an RCCL call failed on some GPU while others had queued their
+ * half) the communicators are aborted (ncclCommAbort) and every call above answers with an error until
+ * rtgpu_group_destroy, which then does not wait for the exchange streams.  A frame every GPU refuses
+ * BEFORE its trace (bad settings, out of memory) queues nothing and leaves the group usable.
+ * Trace-kernel time of the last ended frame on GPU `index` of the list (ms). */
 int  rtgpu_group_kernel_ms(rtgpu_group *g, int index, float *ms);
 
 /* Camera helper: RTIOW look-at thin-lens camera, computed in f64 and rounded

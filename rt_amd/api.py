@@ -158,6 +158,7 @@ lib.rtgpu_group_destroy.restype = None
 lib.rtgpu_group_last_error.argtypes = [C.c_void_p]
 lib.rtgpu_group_last_error.restype = C.c_char_p
 lib.rtgpu_group_size.argtypes = [C.c_void_p]
+lib.rtgpu_group_comm_ranks.argtypes = [C.c_void_p]
 lib.rtgpu_group_upload_scene.argtypes = [C.c_void_p, _P(SceneDesc), C.c_int]
 lib.rtgpu_group_render_begin.argtypes = [C.c_void_p, _P(Camera), _P(Settings)]
 lib.rtgpu_group_render_end.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, _P(Stats)]
@@ -551,6 +552,11 @@ class Group:
             self.close()
         except Exception:
             pass
+
+    @property
+    def comm_ranks(self):
+        """Ranks of the RCCL communicator (0: the tiles move by device copies, a rehearsal)."""
+        return int(lib.rtgpu_group_comm_ranks(self._h))
 
     def upload(self, scene, builder="sah"):
         self._check(lib.rtgpu_group_upload_scene(self._h, C.byref(scene.desc), {"sah": 0, "lbvh": 1}[builder]))

@@ -20,6 +20,7 @@
 #include <rccl/rccl.h>
 
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <mutex>
@@ -35,6 +36,7 @@ struct Rccl {
   void *handle = nullptr;
   ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -50,12 +52,13 @@ struct Rccl {
     auto sym = [&](const char *n) { return dlsym(handle, n); };
     CommInitAll = (decltype(CommInitAll))sym("ncclCommInitAll");
     CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
+    CommAbort = (decltype(CommAbort))sym("ncclCommAbort");
     GroupStart = (decltype(GroupStart))sym("ncclGroupStart");
     GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
     Send = (decltype(Send))sym("ncclSend");
     Recv = (decltype(Recv))sym("ncclRecv");
     GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
-    if (!CommInitAll || !CommDestroy || !GroupStart || !GroupEnd || !Send || !Recv || !GetErrorString) {
+    if (!CommInitAll || !CommDestroy || !CommAbort || !GroupStart || !GroupEnd || !Send || !Recv || !GetErrorString) {
       err = "librccl.so.1 lacks an entry point (ncclCommInitAll / ncclSend / ncclRecv ...)";
       return false;
     }
@@ -106,6 +109,10 @@ struct Frame {
 struct rtgpu_group {
   std::vector<Worker> workers;
   bool use_rccl = true;   // false: a device is listed twice (rehearsal) - peer-to-peer copies instead
+  bool self_rccl = false; // one device + RTGPU_GROUP_SELF_RCCL=1: a one-rank communicator, the root's own buffer goes
+                          // through a grouped ncclSend / ncclRecv to itself (exercises the binding on a one-GPU box)
+  int debug_fail_exchange = -1;  // RTGPU_GROUP_DEBUG_FAIL_EXCHANGE=rank (tests): that rank fails at the start of the exchange step
+  bool broken = false;    // an exchange failed half way: the communicators were aborted, only destroy is left
   std::string err;
   // job hand-off: the caller posts one function, every worker runs it on its GPU
   std::mutex m;
@@ -174,11 +181,6 @@ int run_all(rtgpu_group *g, std::function<int(Worker &)> job) {
     hipError_t e_ = (call);                                                \
     if (e_ != hipSuccess) { w.err = std::string(#call ": ") + hipGetErrorString(e_); return 2; } \
   } while (0)
-#define W_NCCL(call)                                                       \
-  do {                                                                     \
-    ncclResult_t r_ = (call);                                              \
-    if (r_ != ncclSuccess) { w.err = std::string(#call ": ") + g_rccl.GetErrorString(r_); return 2; } \
-  } while (0)
 #define W_RT(call)                                                         \
   do {                                                                     \
     int r_ = (call);                                                       \
@@ -194,14 +196,20 @@ int fail(rtgpu_group *g, int rc, const std::string &msg) {
 
 extern "C" const char *rtgpu_group_last_error(const rtgpu_group *g) { return g ? g->err.c_str() : g_group_error.c_str(); }
 extern "C" int rtgpu_group_size(const rtgpu_group *g) { return g ? (int)g->workers.size() : 0; }
+extern "C" int rtgpu_group_comm_ranks(const rtgpu_group *g) {
+  if (!g || g->workers.empty() || !g->workers[0].comm) return 0;
+  return (int)g->workers.size();
+}
 
 extern "C" void rtgpu_group_destroy(rtgpu_group *g) {
   if (!g) return;
+  const bool broken = g->broken;  // aborted communicators: their streams may hold work that never completes
   if (!g->workers.empty() && g->workers[0].thread.joinable()) {
-    run_all(g, [](Worker &w) {  // everything queued on this GPU has to be over before its buffers go
-      (void)hipDeviceSynchronize();
-      return 0;
-    });
+    if (!broken)
+      run_all(g, [](Worker &w) {  // everything queued on this GPU has to be over before its buffers go
+        (void)hipDeviceSynchronize();
+        return 0;
+      });
     {
       std::lock_guard<std::mutex> lk(g->m);
       g->quit = true;
@@ -213,6 +221,13 @@ extern "C" void rtgpu_group_destroy(rtgpu_group *g) {
   for (Worker &w : g->workers) {
     if (!w.ctx) continue;  // never set up (rtgpu_group_create failed before it)
     (void)hipSetDevice(w.device);
+    if (broken) {
+      // the trace stream's work is finite; the exchange stream is left alone (abort_comms ended its
+      // collectives, and buffers it might still name are deliberately leaked rather than freed under it)
+      if (w.trace_stream) (void)hipStreamSynchronize(w.trace_stream);
+      rtgpu_internal_abandon(w.ctx);
+      continue;
+    }
     (void)hipDeviceSynchronize();
     if (w.comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(w.comm);
     w.compact.release();
@@ -261,7 +276,12 @@ extern "C" int rtgpu_group_create(rtgpu_group **out, const int *devices, int n) 
     }
     if (e != hipSuccess) return bail(2, std::string("rtgpu_group_create: ") + hipGetErrorString(e));
   }
-  if (g->use_rccl && n > 1) {
+  if (const char *env = std::getenv("RTGPU_GROUP_DEBUG_FAIL_EXCHANGE")) g->debug_fail_exchange = std::atoi(env);
+  if (n == 1) {
+    const char *env = std::getenv("RTGPU_GROUP_SELF_RCCL");
+    g->self_rccl = env && std::atoi(env) != 0;
+  }
+  if (g->use_rccl && (n > 1 || g->self_rccl)) {
     std::string lerr;
     if (!g_rccl.load(lerr)) return bail(2, "rtgpu_group_create: " + lerr);
     std::vector<ncclComm_t> comms((size_t)n);
@@ -286,6 +306,7 @@ extern "C" int rtgpu_group_create(rtgpu_group **out, const int *devices, int n) 
 
 extern "C" int rtgpu_group_upload_scene(rtgpu_group *g, const rtgpu_scene_desc *scene, int builder) {
   if (!g) return 1;
+  if (g->broken) return fail(g, 2, "the group is unusable after a failed exchange (destroy it and create a new one)");
   if (g->begun != g->ended) return fail(g, 1, "a frame is in flight (call rtgpu_group_render_end first)");
   g->resident = false;
   if (builder == 1)  // every GPU builds its own LBVH from the primitives: same bytes everywhere (collapse4.hip)
@@ -306,8 +327,28 @@ extern "C" int rtgpu_group_upload_scene(rtgpu_group *g, const rtgpu_scene_desc *
   return rc;
 }
 
+namespace {
+// An exchange failed on some GPU while others may already have queued their half of it: end every
+// communicator's pending work (ncclCommAbort makes in-flight RCCL kernels exit) and leave the group
+// usable for nothing but rtgpu_group_destroy, which then does not wait for the exchange streams.
+int break_group(rtgpu_group *g, int rc, const std::string &msg) {
+  if (g_rccl.CommAbort)
+    for (Worker &w : g->workers)
+      if (w.comm) {
+        (void)hipSetDevice(w.device);
+        (void)g_rccl.CommAbort(w.comm);
+        w.comm = nullptr;
+      }
+  g->broken = true;
+  g->resident = false;
+  g->err = msg + " (the group is unusable now: destroy it and create a new one)";
+  return rc;
+}
+}  // namespace
+
 extern "C" int rtgpu_group_render_begin(rtgpu_group *g, const rtgpu_camera *cam, const rtgpu_settings *s) {
   if (!g) return 1;
+  if (g->broken) return fail(g, 2, "the group is unusable after a failed exchange (destroy it and create a new one)");
   if (!cam || !s) return fail(g, 1, "camera or settings is NULL");
   if (g->begun - g->ended >= 2) return fail(g, 1, "two frames are in flight already (call rtgpu_group_render_end)");
   const int n = (int)g->workers.size();
@@ -320,6 +361,8 @@ extern "C" int rtgpu_group_render_begin(rtgpu_group *g, const rtgpu_camera *cam,
   g->resident = false;
   rtgpu_group *gp = g;
   Worker *root = &g->workers[0];
+  // phase 1a, every GPU: buffers and the trace of its tiles.  Nothing touches an exchange stream yet, so a failure
+  // here (out of memory, a refused setting) leaves no half of an exchange queued anywhere: the frame is simply not begun.
   int rc = run_all(g, [=](Worker &w) {
     W_HIP(w.compact.want(n_pad * 16));
     W_HIP(w.send[b].want(n_pad * 16));
@@ -344,20 +387,35 @@ extern "C" int rtgpu_group_render_begin(rtgpu_group *g, const rtgpu_camera *cam,
     W_HIP(hipStreamWaitEvent(w.trace_stream, w.ev_sent[b], 0));
     W_HIP(hipMemcpyAsync(w.send[b].p, w.compact.p, n_pad * 16, hipMemcpyDeviceToDevice, w.trace_stream));
     W_HIP(hipEventRecord(w.ev_traced[b], w.trace_stream));
+    return 0;
+  });
+  if (rc) return rc;  // (a frame with RTGPU_FLAG_ACCUMULATE after this starts a fresh sum: resident is false)
+  // phase 1b, every GPU: the one exchange step of the frame - every peer straight to the root.  Reached only when
+  // every GPU has traced, so each ncclRecv the root queues has its ncclSend.
+  rc = run_all(g, [=](Worker &w) {
+    if (w.index == gp->debug_fail_exchange) { w.err = "exchange failure injected (RTGPU_GROUP_DEBUG_FAIL_EXCHANGE)"; return 2; }
     W_HIP(hipStreamWaitEvent(w.comm_stream, w.ev_traced[b], 0));
     const size_t count = (size_t)n_pad * 4;  // floats
-    if (w.index == 0)
+    const bool self = gp->self_rccl && w.comm;
+    if (w.index == 0 && !self)
       W_HIP(hipMemcpyAsync(w.gathered[b].p, w.send[b].p, n_pad * 16, hipMemcpyDeviceToDevice, w.comm_stream));
-    if (n > 1 && gp->use_rccl) {
-      // the one exchange step of the frame: every peer straight to the root
-      W_NCCL(g_rccl.GroupStart());
+    if ((n > 1 && gp->use_rccl) || self) {
+      ncclResult_t r = g_rccl.GroupStart();
+      if (r != ncclSuccess) { w.err = std::string("ncclGroupStart: ") + g_rccl.GetErrorString(r); return 2; }
+      // a failed call inside the group still meets its ncclGroupEnd: the thread's RCCL group must not stay open
       if (w.index == 0) {
-        for (int r = 1; r < n; r++)
-          W_NCCL(g_rccl.Recv((char *)w.gathered[b].p + (size_t)r * n_pad * 16, count, ncclFloat, r, w.comm, w.comm_stream));
+        for (int q = 1; q < n && r == ncclSuccess; q++)
+          r = g_rccl.Recv((char *)w.gathered[b].p + (size_t)q * n_pad * 16, count, ncclFloat, q, w.comm, w.comm_stream);
+        if (self && r == ncclSuccess) {  // one-rank communicator: the root's own part travels through RCCL too
+          r = g_rccl.Send(w.send[b].p, count, ncclFloat, 0, w.comm, w.comm_stream);
+          if (r == ncclSuccess) r = g_rccl.Recv(w.gathered[b].p, count, ncclFloat, 0, w.comm, w.comm_stream);
+        }
       } else {
-        W_NCCL(g_rccl.Send(w.send[b].p, count, ncclFloat, 0, w.comm, w.comm_stream));
+        r = g_rccl.Send(w.send[b].p, count, ncclFloat, 0, w.comm, w.comm_stream);
       }
-      W_NCCL(g_rccl.GroupEnd());
+      const ncclResult_t r_end = g_rccl.GroupEnd();
+      if (r != ncclSuccess) { w.err = std::string("ncclSend / ncclRecv: ") + g_rccl.GetErrorString(r); return 2; }
+      if (r_end != ncclSuccess) { w.err = std::string("ncclGroupEnd: ") + g_rccl.GetErrorString(r_end); return 2; }
     } else if (n > 1 && w.index != 0) {
       // rehearsal transport (a device listed twice): the peer writes its part into the root's buffer.
       // root->gathered[b] was sized by the root's own job; both jobs run before the caller's phase 2.
@@ -365,7 +423,7 @@ extern "C" int rtgpu_group_render_begin(rtgpu_group *g, const rtgpu_camera *cam,
     }
     return 0;
   });
-  if (rc) return rc;
+  if (rc) return break_group(g, rc, g->err);
   // phase 2, from the calling thread (the workers are idle again): what needs every GPU's phase 1
   if (n > 1 && !g->use_rccl) {
     for (int r = 1; r < n; r++) {
@@ -373,25 +431,25 @@ extern "C" int rtgpu_group_render_begin(rtgpu_group *g, const rtgpu_camera *cam,
       if (hipSetDevice(w.device) != hipSuccess ||
           hipMemcpyAsync((char *)root->gathered[b].p + (size_t)r * n_pad * 16, w.send[b].p, n_pad * 16, hipMemcpyDeviceToDevice,
                          w.comm_stream) != hipSuccess)
-        return fail(g, 2, "peer copy of a tile buffer failed");
+        return break_group(g, 2, "peer copy of a tile buffer failed");
     }
   }
   for (Worker &w : g->workers) {
     hipError_t e = hipSetDevice(w.device);
     if (e == hipSuccess) e = hipEventRecord(w.ev_sent[b], w.comm_stream);
-    if (e != hipSuccess) return fail(g, 2, std::string("hipEventRecord: ") + hipGetErrorString(e));
+    if (e != hipSuccess) return break_group(g, 2, std::string("hipEventRecord: ") + hipGetErrorString(e));
   }
   {
     hipError_t e = hipSetDevice(root->device);
     if (e == hipSuccess && n > 1 && !g->use_rccl)
       for (int r = 1; r < n && e == hipSuccess; r++) e = hipStreamWaitEvent(root->comm_stream, g->workers[(size_t)r].ev_sent[b], 0);
-    if (e != hipSuccess) return fail(g, 2, std::string("group exchange: ") + hipGetErrorString(e));
+    if (e != hipSuccess) return break_group(g, 2, std::string("group exchange: ") + hipGetErrorString(e));
     if (rtgpu_untile_device(root->ctx, root->gathered[b].p, root->image[b].p, s->width, s->height, s->tile_size, (uint32_t)n, 16,
                             root->comm_stream) ||
         rtgpu_resolve_rgba8_device(root->ctx, root->image[b].p, root->rgba[b].p, n_px, root->comm_stream))
-      return fail(g, 2, rtgpu_last_error(root->ctx));
+      return break_group(g, 2, rtgpu_last_error(root->ctx));
     e = hipEventRecord(root->ev_frame[b], root->comm_stream);
-    if (e != hipSuccess) return fail(g, 2, std::string("hipEventRecord: ") + hipGetErrorString(e));
+    if (e != hipSuccess) return break_group(g, 2, std::string("hipEventRecord: ") + hipGetErrorString(e));
   }
   g->frames[b].width = s->width;
   g->frames[b].height = s->height;
@@ -404,6 +462,7 @@ extern "C" int rtgpu_group_render_begin(rtgpu_group *g, const rtgpu_camera *cam,
 
 extern "C" int rtgpu_group_render_end(rtgpu_group *g, float *accum_rgba, uint32_t *rgba8, rtgpu_stats *stats) {
   if (!g) return 1;
+  if (g->broken) return fail(g, 2, "the group is unusable after a failed exchange (destroy it and create a new one)");
   if (g->begun == g->ended) return fail(g, 1, "no frame is in flight (call rtgpu_group_render_begin first)");
   const int b = (int)(g->ended & 1);
   g->ended++;

@@ -69,6 +69,9 @@ int  check_prims_device(const void *d_spheres, uint32_t ns, const void *d_triang
 // rtgpu_kernels.hip, for group.cpp: an already flattened scene of this process to one more GPU
 extern "C" int rtgpu_internal_upload_flat(rtgpu_ctx *ctx, const rtgpu_flat_scene *fs, int take_ownership);
 extern "C" int rtgpu_internal_counters(rtgpu_ctx *ctx, uint64_t **d_counters);
+// group.cpp, after a failed exchange: drops the context WITHOUT waiting for the device (a stream of it may
+// hold work that never completes) and without freeing device memory that such work might still name.
+extern "C" void rtgpu_internal_abandon(rtgpu_ctx *ctx);
 namespace rtgpu {
 
 // host_util.cpp

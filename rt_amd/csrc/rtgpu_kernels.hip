@@ -1896,6 +1896,7 @@ extern "C" int rtgpu_refit(rtgpu_ctx *ctx, const rtgpu_scene_desc *scene) {
     return rc;
   }
   h.build_ms = ms;
+  ctx->res_valid = false;  // new geometry: rtgpu_render_resolved starts its sum again (include/rtgpu.h)
   return 0;
 }
 
@@ -1933,6 +1934,7 @@ extern "C" int rtgpu_refit_device(rtgpu_ctx *ctx, const void *d_spheres, uint64_
     return rc;
   }
   h.build_ms = ms;
+  ctx->res_valid = false;  // new geometry: rtgpu_render_resolved starts its sum again (include/rtgpu.h)
   return 0;
 }
 
@@ -2298,6 +2300,12 @@ extern "C" int rtgpu_internal_counters(rtgpu_ctx *ctx, uint64_t **d_counters) {
   if (!ctx || !d_counters) return 1;
   *d_counters = (uint64_t *)ctx->d_counters;
   return 0;
+}
+
+extern "C" void rtgpu_internal_abandon(rtgpu_ctx *ctx) {
+  if (!ctx) return;
+  rtgpu::free_flat_scene(&ctx->host);  // host memory only; device buffers, events and streams are leaked on purpose
+  delete ctx;
 }
 
 extern "C" const char *rtgpu_last_kernel_name(const rtgpu_ctx *ctx) { return ctx ? ctx->kernel_name : ""; }

@@ -104,6 +104,64 @@ void rt_render_resolved_or_panic(Camera const &cam, Render_Settings const &setti
     errf("rt: render failed: %s", ::rtgpu_last_error(gRt_Ctx));
 }
 
+void rt_panel_init(Rt_Panel_State &panel, u32 width, u32 height) {
+  panel = Rt_Panel_State{};
+  panel.width  = width;
+  panel.height = height;
+  panel.cam_from.x = 13.f; panel.cam_from.y = 2.f; panel.cam_from.z = 3.f;   // S0's cover camera
+  panel.vfov_deg   = 20.f;
+  panel.aperture   = 0.f;
+  panel.focus_dist = 10.f;
+  panel.settings   = rt_default_settings(width, height, 1, RT_MAX_DEPTH);
+  panel.restart    = true;
+}
+
+void rt_panel_apply(Rt_Panel_State &panel, Rt_Panel_Edit const &edit) {
+  if (edit.set_spp) panel.settings.spp = edit.spp < 1u ? 1u : edit.spp;   // no restart: the sum just grows faster
+  if (edit.set_depth) {
+    u32 const d = edit.max_depth < 1u ? 1u : edit.max_depth;
+    if (d != panel.settings.max_depth) panel.restart = true;
+    panel.settings.max_depth = d;
+  }
+  if (edit.set_camera) {
+    panel.cam_from   = edit.cam_from;
+    panel.cam_at     = edit.cam_at;
+    panel.vfov_deg   = edit.vfov_deg < 1.f ? 1.f : (edit.vfov_deg > 179.f ? 179.f : edit.vfov_deg);
+    panel.aperture   = edit.aperture < 0.f ? 0.f : edit.aperture;
+    panel.focus_dist = edit.focus_dist > 1e-3f ? edit.focus_dist : 1e-3f;
+    panel.restart    = true;
+  }
+  if (edit.set_sky) {
+    for (int k = 0; k < 3; k++) {
+      panel.settings.sky_bottom[k] = edit.sky_bottom[k];
+      panel.settings.sky_top[k]    = edit.sky_top[k];
+    }
+    panel.restart = true;
+  }
+  if (edit.restart_pressed) panel.restart = true;
+}
+
+void rt_panel_step_or_panic(Rt_Panel_State &panel, u32 *rgba8_out) {
+  if (panel.restart) {
+    Vec3 up; up.x = 0.f; up.y = 1.f; up.z = 0.f;
+    panel.camera = rt_camera_look_at(panel.cam_from, panel.cam_at, up, panel.vfov_deg,
+                                     (f32)panel.width / (f32)panel.height, panel.aperture, panel.focus_dist);
+    panel.settings.sample_offset = 0;
+    panel.settings.flags &= ~(u32)RTGPU_FLAG_ACCUMULATE;   // this frame starts the sum on the GPU
+    panel.samples_shown = 0;
+    panel.frames_since_restart = 0;
+    panel.restart = false;
+  }
+  Render_Stats stats = {};
+  rt_render_resolved_or_panic(panel.camera, panel.settings, rgba8_out, &stats);
+  panel.settings.sample_offset += panel.settings.spp;
+  panel.settings.flags |= RTGPU_FLAG_ACCUMULATE;
+  panel.samples_shown += panel.settings.spp;
+  panel.frames_since_restart++;
+  f32 const ms = rt_last_kernel_ms();
+  if (ms > 0.f) panel.mrays_per_s = (f32)((double)stats.rays / ((double)ms * 1e3));
+}
+
 void rt_resolve_rgba8_or_panic(Vec4 const *accum, u32 *rgba8_out, s64 pixel_count) {
   if (::rtgpu_resolve_rgba8(gRt_Ctx, (float const *)accum, rgba8_out, (uint64_t)pixel_count) != 0)
     errf("rt: resolve failed: %s", ::rtgpu_last_error(gRt_Ctx));

@@ -124,6 +124,42 @@ void rt_render_end_or_panic(Render_Stats *stats_out = nullptr);
 void rt_render_resolved_or_panic(Camera const &cam, Render_Settings const &settings, u32 *rgba8_out,
                                  Render_Stats *stats_out = nullptr);
 
+// ---- the control panel's state machine, platform-free --------------------
+// What the ImGui panel that replaces ShowDemoWindow (code/imgui/imgui.cpp:25-26) drives, kept apart
+// from ImGui and D3D11 so that it runs (and is tested) wherever the trace loop does: the widgets
+// only FILL an Rt_Panel_Edit per UI frame (win32_patch/rt_present.cxx), rt_headless --script feeds
+// the same struct from a text file.
+struct Rt_Panel_State {
+  u32    width, height;
+  Vec3   cam_from, cam_at;
+  f32    vfov_deg, aperture, focus_dist;
+  Camera          camera;        // rebuilt from the fields above when the accumulation restarts
+  Render_Settings settings;      // settings.spp = samples traced per displayed frame
+  bool   restart;                // the next frame starts the accumulation again
+  u32    samples_shown;          // samples in the frame on screen
+  u32    frames_since_restart;
+  f32    mrays_per_s;            // readout: rays of the last frame / its trace-kernel time
+};
+// One UI frame's worth of widget results; a field is read only if its `set_` flag is true.
+struct Rt_Panel_Edit {
+  bool set_spp;     u32 spp;
+  bool set_depth;   u32 max_depth;
+  bool set_camera;  Vec3 cam_from, cam_at; f32 vfov_deg, aperture, focus_dist;
+  bool set_sky;     f32 sky_bottom[3], sky_top[3];
+  bool restart_pressed;
+};
+// Defaults: the cover camera of scene S0, 1 spp per displayed frame (progressive), RT_MAX_DEPTH.
+void rt_panel_init(Rt_Panel_State &panel, u32 width, u32 height);
+// Anything that changes what a sample computes (depth, camera, lens, sky) restarts the accumulation;
+// samples per frame does not (it only changes how fast the sum grows).  Values are clamped to what
+// rtgpu_settings accepts (spp, depth >= 1; vfov in [1, 179]; aperture >= 0; focus > 0).
+void rt_panel_apply(Rt_Panel_State &panel, Rt_Panel_Edit const &edit);
+// One iteration of the frame loop (code/first.cpp:78-88): settings.spp more samples through
+// rt_render_resolved_or_panic - a fresh sum with sample_offset 0 after a restart, otherwise
+// RTGPU_FLAG_ACCUMULATE at the running offset - then the offset, sample count and Mrays/s readout
+// advance.  rgba8_out: width*height u32 (0xRRGGBBAA, row 0 = bottom), caller-owned.
+void rt_panel_step_or_panic(Rt_Panel_State &panel, u32 *rgba8_out);
+
 // accum -> 0xRRGGBBAA (gamma 2), ready for a B8G8R8A8/R8G8B8A8 upload.
 void rt_resolve_rgba8_or_panic(Vec4 const *accum, u32 *rgba8_out, s64 pixel_count);
 

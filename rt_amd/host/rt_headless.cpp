@@ -11,6 +11,15 @@
 //                     tile gather to GPU 0), frames pipelined two deep
 //   --devices a,b,..  the same with an explicit device list; a device listed twice rehearses
 //                     several ranks on one GPU (tile buffers then move by device copies)
+//   --camera-matrix m00,m01,..,m33   camera-to-world Mat4x4 in the reference's row-vector convention
+//                     (rows right / up / back / eye, code/math/mat.cxx:12-20,93-102) through
+//                     rt_camera_from_basis; --vfov DEG goes with it (default 20)
+//   --obj-via buffer  an OBJ scene is read into a Buffer first (what os_read_entire_file_or_panic
+//                     returns, code/first.hpp:29-32) and parsed with rt_scene_parse_obj_or_panic
+//   --script FILE     the control panel's state machine (rt_panel_*, rt.hpp) fed from a text file in place
+//                     of ImGui widgets, one command per line: `spp N`, `depth N`, `camera fx fy fz ax ay az
+//                     vfov aperture focus`, `sky br bg bb tr tg tb`, `restart`, and `frame` = one iteration of
+//                     the frame loop, whose resolved frame is written to <out>.<k>.ppm (k counts frames from 0)
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -36,6 +45,10 @@ using namespace rt;
 
 int main(int argc, char **argv) {
   int devices[64], n_devices = 0, frames = 0;
+  bool have_matrix = false, obj_via_buffer = false;
+  Mat4x4 cam_matrix = {};
+  f32 vfov = 20.f;
+  char const *script_path = nullptr;
   while (argc > 1 && argv[1][0] == '-' && argv[1][1] == '-') {
     if (argc < 3) errf("%s needs a value", argv[1]);
     if (!std::strcmp(argv[1], "--gpus")) {
@@ -45,6 +58,18 @@ int main(int argc, char **argv) {
     } else if (!std::strcmp(argv[1], "--devices")) {
       for (char *tok = std::strtok(argv[2], ","); tok && n_devices < 64; tok = std::strtok(nullptr, ",")) devices[n_devices++] = std::atoi(tok);
       if (n_devices < 1) errf("--devices a,b,...");
+    } else if (!std::strcmp(argv[1], "--camera-matrix")) {
+      int k = 0;
+      for (char *tok = std::strtok(argv[2], ","); tok && k < 16; tok = std::strtok(nullptr, ","), k++) cam_matrix.v[k / 4][k % 4] = std::strtof(tok, nullptr);
+      if (k != 16) errf("--camera-matrix takes 16 comma-separated numbers, got %d", k);
+      have_matrix = true;
+    } else if (!std::strcmp(argv[1], "--vfov")) {
+      vfov = std::strtof(argv[2], nullptr);
+    } else if (!std::strcmp(argv[1], "--obj-via")) {
+      if (!std::strcmp(argv[2], "buffer")) obj_via_buffer = true;
+      else if (std::strcmp(argv[2], "path")) errf("--obj-via buffer|path");
+    } else if (!std::strcmp(argv[1], "--script")) {
+      script_path = argv[2];
     } else if (!std::strcmp(argv[1], "--frames")) {
       frames = std::atoi(argv[2]);
       if (frames < 1) errf("--frames >= 1");
@@ -72,7 +97,23 @@ int main(int argc, char **argv) {
   Camera cam;
   Scene scene;
   if (from_file) {
-    scene = rt_scene_load_obj_or_panic(argv[1]);
+    if (obj_via_buffer) {
+      // the reference's file idiom: the whole file in a Buffer, then the parser (os_read_entire_file_or_panic
+      // is Win32-only, code/os/filesystem.cxx:2-60; plain stdio stands in for it here)
+      std::FILE *f = std::fopen(argv[1], "rb");
+      if (!f) errf("cannot open %s", argv[1]);
+      std::fseek(f, 0, SEEK_END);
+      Buffer file = {};
+      file.count = (s64)std::ftell(f);
+      std::fseek(f, 0, SEEK_SET);
+      file.bytes = (u8 *)std::malloc(file.count > 0 ? (size_t)file.count : 1);
+      if (!file.bytes || std::fread(file.bytes, 1, (size_t)file.count, f) != (size_t)file.count) errf("cannot read %s", argv[1]);
+      std::fclose(f);
+      scene = rt_scene_parse_obj_or_panic(file);
+      std::free(file.bytes);   // the parser copies: the Buffer stays the caller's
+    } else {
+      scene = rt_scene_load_obj_or_panic(argv[1]);
+    }
     if (scene.triangles_count == 0) errf("%s holds no faces", argv[1]);
     Vec3 lo = scene.triangles[0].v0, hi = lo;
     for (s64 i = 0; i < scene.triangles_count; i++) {
@@ -101,6 +142,7 @@ int main(int argc, char **argv) {
                   (Triangle *)builtin.triangles, (s64)builtin.n_triangles,
                   (Material *)builtin.materials, (s64)builtin.n_materials};
   }
+  if (have_matrix) cam = rt_camera_from_basis(cam_matrix, vfov, (f32)width / (f32)height);
   if (multi) rt_scene_upload_multi_or_panic(scene);
   else rt_scene_upload_or_panic(scene);
 
@@ -115,7 +157,59 @@ int main(int argc, char **argv) {
   s64 pumped = 0;
   double kernel_ms = 0.0;
   unsigned long long rays = 0;
-  if (multi) {
+  int script_frames = 0;
+  if (script_path) {
+    // rows f4 of SURVEY.md §8: the panel's state machine, fed from a file where the ImGui widgets would feed it
+    if (multi) errf("--script drives the one-GPU progressive loop");
+    std::FILE *f = std::fopen(script_path, "r");
+    if (!f) errf("cannot open %s", script_path);
+    Rt_Panel_State panel;
+    rt_panel_init(panel, width, height);
+    {  // the command line's spp / depth are the panel's starting values
+      Rt_Panel_Edit e = {};
+      e.set_spp = true; e.spp = spp;
+      e.set_depth = true; e.max_depth = depth;
+      rt_panel_apply(panel, e);
+    }
+    char line[512];
+    while (std::fgets(line, sizeof(line), f)) {
+      Rt_Panel_Edit e = {};
+      char cmd[32] = "";
+      if (std::sscanf(line, "%31s", cmd) != 1 || cmd[0] == '#') continue;
+      char const *rest = std::strstr(line, cmd) + std::strlen(cmd);
+      if (!std::strcmp(cmd, "frame")) {
+        rt_panel_step_or_panic(panel, rgba);
+        char path[1024];
+        std::snprintf(path, sizeof(path), "%s.%d.ppm", out_path, script_frames);
+        rt_write_ppm_or_panic(path, rgba, width, height);
+        std::printf("frame %d: %u samples shown, offset now %u, %.0f Mrays/s -> %s\n", script_frames, panel.samples_shown,
+                    panel.settings.sample_offset, (double)panel.mrays_per_s, path);
+        script_frames++;
+        continue;
+      } else if (!std::strcmp(cmd, "spp")) {
+        e.set_spp = std::sscanf(rest, "%u", &e.spp) == 1;
+        if (!e.set_spp) errf("script: spp N");
+      } else if (!std::strcmp(cmd, "depth")) {
+        e.set_depth = std::sscanf(rest, "%u", &e.max_depth) == 1;
+        if (!e.set_depth) errf("script: depth N");
+      } else if (!std::strcmp(cmd, "camera")) {
+        e.set_camera = std::sscanf(rest, "%f %f %f %f %f %f %f %f %f", &e.cam_from.x, &e.cam_from.y, &e.cam_from.z, &e.cam_at.x,
+                                   &e.cam_at.y, &e.cam_at.z, &e.vfov_deg, &e.aperture, &e.focus_dist) == 9;
+        if (!e.set_camera) errf("script: camera fx fy fz ax ay az vfov aperture focus");
+      } else if (!std::strcmp(cmd, "sky")) {
+        e.set_sky = std::sscanf(rest, "%f %f %f %f %f %f", &e.sky_bottom[0], &e.sky_bottom[1], &e.sky_bottom[2], &e.sky_top[0],
+                                &e.sky_top[1], &e.sky_top[2]) == 6;
+        if (!e.set_sky) errf("script: sky br bg bb tr tg tb");
+      } else if (!std::strcmp(cmd, "restart")) {
+        e.restart_pressed = true;
+      } else {
+        errf("script: unknown command %s", cmd);
+      }
+      rt_panel_apply(panel, e);
+    }
+    std::fclose(f);
+    kernel_ms = rt_last_kernel_ms();
+  } else if (multi) {
     // frames pipelined two deep: the gather of frame k runs beside the trace of frame k+1
     int const n_frames = frames ? frames : 1;
     for (int f = 0; f <= n_frames; f++) {

@@ -10,9 +10,8 @@ Rt_Present gRt_Present = {};
 
 void rt_present_init_or_panic(u32 width, u32 height) {
   auto &P = gRt_Present;
-  P.width  = width;
-  P.height = height;
-  P.rgba   = (u32 *)alloc_perm((s64)width * height * (s64)sizeof(u32));
+  rt_panel_init(P.panel, width, height);
+  P.rgba = (u32 *)alloc_perm((s64)width * height * (s64)sizeof(u32));
 
   ::D3D11_TEXTURE2D_DESC desc = {};
   desc.Width            = width;
@@ -34,13 +33,6 @@ void rt_present_init_or_panic(u32 width, u32 height) {
   hr = gD3d.device->CreateShaderResourceView(P.texture, &view_desc, &P.view);
   d3d_check_hresult_(hr);
 
-  P.cam_from   = {13.f, 2.f, 3.f};
-  P.cam_at     = {0.f, 0.f, 0.f};
-  P.vfov_deg   = 20.f;
-  P.aperture   = 0.f;
-  P.focus_dist = 10.f;
-  P.settings   = rt_default_settings(width, height, 1, RT_MAX_DEPTH);   // progressive: 1 spp per displayed frame
-  P.restart    = true;
 }
 
 void rt_present_shutdown() {
@@ -53,10 +45,11 @@ void rt_present_upload(u32 const *rgba8) {
   ::D3D11_MAPPED_SUBRESOURCE mapped = {};
   ::HRESULT hr = gD3d.device_context->Map(P.texture, 0, D3D11_MAP_WRITE_DISCARD, 0, &mapped);
   d3d_check_hresult_(hr);
-  for (u32 y = 0; y < P.height; y++) {
-    u32 const *src = rgba8 + (s64)(P.height - 1 - y) * P.width;          // frame row 0 is the bottom row
+  u32 const width = P.panel.width, height = P.panel.height;
+  for (u32 y = 0; y < height; y++) {
+    u32 const *src = rgba8 + (s64)(height - 1 - y) * width;              // frame row 0 is the bottom row
     u8        *dst = (u8 *)mapped.pData + (s64)y * mapped.RowPitch;
-    for (u32 x = 0; x < P.width; x++) {
+    for (u32 x = 0; x < width; x++) {
       u32 const c = src[x];                                              // 0xRRGGBBAA (gfx.hpp:4-6)
       dst[4 * x + 0] = (u8)(c >> 24);
       dst[4 * x + 1] = (u8)(c >> 16);
@@ -69,44 +62,36 @@ void rt_present_upload(u32 const *rgba8) {
 
 void rt_present_frame_or_panic() {
   auto &P = gRt_Present;
-  if (P.restart) {
-    P.camera = rt_camera_look_at(P.cam_from, P.cam_at, {0.f, 1.f, 0.f}, P.vfov_deg,
-                                 (f32)P.width / (f32)P.height, P.aperture, P.focus_dist);
-    P.settings.sample_offset = 0;
-    P.settings.flags &= ~(u32)RTGPU_FLAG_ACCUMULATE;     // this frame starts the sum on the GPU
-    P.samples_shown = 0;
-    P.restart = false;
-  }
-  Render_Stats stats = {};
-  rt_render_resolved_or_panic(P.camera, P.settings, P.rgba, &stats);
-  P.settings.sample_offset += P.settings.spp;
-  P.settings.flags |= RTGPU_FLAG_ACCUMULATE;
-  P.samples_shown += P.settings.spp;
-  f32 const ms = rt_last_kernel_ms();
-  if (ms > 0.f) P.mrays_per_s = (f32)((f64)stats.rays / ((f64)ms * 1e3));
+  rt_panel_step_or_panic(P.panel, P.rgba);   // the whole state machine lives in rt.cpp (tested on Linux)
   rt_present_upload(P.rgba);
 }
 
+// The widgets only fill an Rt_Panel_Edit; what restarts the accumulation is rt_panel_apply's business.
 void rt_present_panel() {
   auto &P = gRt_Present;
+  auto &S = P.panel;
   ImGui::Begin("rt");
-  ImGui::Image((ImTextureID)P.view, ImVec2((f32)P.width, (f32)P.height));
+  ImGui::Image((ImTextureID)P.view, ImVec2((f32)S.width, (f32)S.height));
   ImGui::End();
 
   ImGui::Begin("trace settings");
-  ImGui::Text("%u samples shown, %.0f Mrays/s (trace kernel)", P.samples_shown, P.mrays_per_s);
-  int spp = (int)P.settings.spp, depth = (int)P.settings.max_depth;
-  // anything that changes what a sample computes restarts the accumulation; spp per frame does not
-  if (ImGui::SliderInt("samples per frame", &spp, 1, 64)) P.settings.spp = (u32)spp;
-  if (ImGui::SliderInt("max depth", &depth, 1, 32)) { P.settings.max_depth = (u32)depth; P.restart = true; }
-  P.restart |= ImGui::DragFloat3("camera from", P.cam_from.v, 0.05f);
-  P.restart |= ImGui::DragFloat3("camera at", P.cam_at.v, 0.05f);
-  P.restart |= ImGui::SliderFloat("vertical fov", &P.vfov_deg, 5.f, 120.f);
-  P.restart |= ImGui::SliderFloat("aperture", &P.aperture, 0.f, 1.f);
-  P.restart |= ImGui::SliderFloat("focus distance", &P.focus_dist, 0.1f, 50.f);
-  P.restart |= ImGui::ColorEdit3("sky, horizon", P.settings.sky_bottom);
-  P.restart |= ImGui::ColorEdit3("sky, zenith", P.settings.sky_top);
-  if (ImGui::Button("restart accumulation")) P.restart = true;
+  ImGui::Text("%u samples shown, %.0f Mrays/s (trace kernel)", S.samples_shown, S.mrays_per_s);
+  Rt_Panel_Edit edit = {};
+  int spp = (int)S.settings.spp, depth = (int)S.settings.max_depth;
+  if (ImGui::SliderInt("samples per frame", &spp, 1, 64)) { edit.set_spp = true; edit.spp = (u32)spp; }
+  if (ImGui::SliderInt("max depth", &depth, 1, 32)) { edit.set_depth = true; edit.max_depth = (u32)depth; }
+  edit.cam_from = S.cam_from; edit.cam_at = S.cam_at;
+  edit.vfov_deg = S.vfov_deg; edit.aperture = S.aperture; edit.focus_dist = S.focus_dist;
+  edit.set_camera |= ImGui::DragFloat3("camera from", edit.cam_from.v, 0.05f);
+  edit.set_camera |= ImGui::DragFloat3("camera at", edit.cam_at.v, 0.05f);
+  edit.set_camera |= ImGui::SliderFloat("vertical fov", &edit.vfov_deg, 5.f, 120.f);
+  edit.set_camera |= ImGui::SliderFloat("aperture", &edit.aperture, 0.f, 1.f);
+  edit.set_camera |= ImGui::SliderFloat("focus distance", &edit.focus_dist, 0.1f, 50.f);
+  for (int k = 0; k < 3; k++) { edit.sky_bottom[k] = S.settings.sky_bottom[k]; edit.sky_top[k] = S.settings.sky_top[k]; }
+  edit.set_sky |= ImGui::ColorEdit3("sky, horizon", edit.sky_bottom);
+  edit.set_sky |= ImGui::ColorEdit3("sky, zenith", edit.sky_top);
+  edit.restart_pressed = ImGui::Button("restart accumulation");
   ImGui::End();
+  rt_panel_apply(S, edit);
 }
 }  // namespace rt

@@ -7,22 +7,16 @@ namespace rt {
 struct Rt_Present {
   ITexture2D                 *texture;        // d3d_layer.hxx aliases
   ::ID3D11ShaderResourceView *view;
-  u32    width, height;
   u32   *rgba;                 // width*height resolved frame, alloc_perm (base/memory.cxx:23-34)
-  Camera          camera;
-  Render_Settings settings;    // spp = samples traced per displayed frame
-  Vec3   cam_from, cam_at;
-  f32    vfov_deg, aperture, focus_dist;
-  bool   restart;              // the next frame starts the accumulation again
-  f32    mrays_per_s;          // readout: rays of the last frame / its trace-kernel time
-  u32    samples_shown;
+  Rt_Panel_State panel;        // rt.hpp: camera, settings, restart flag, readouts - the platform-free
+                               // state machine that rt_headless --script runs on Linux (tests/test_headless.py)
 };
 extern Rt_Present gRt_Present;
 
 void rt_present_init_or_panic(u32 width, u32 height);
 void rt_present_shutdown();
-// One iteration of the frame loop: trace settings.spp more samples (rt_render_resolved_or_panic:
-// the float sums stay on the GPU), then rt_present_upload.
+// One iteration of the frame loop: rt_panel_step_or_panic (settings.spp more samples, the float sums
+// stay on the GPU), then rt_present_upload.
 void rt_present_frame_or_panic();
 // rgba8 (0xRRGGBBAA, row 0 = bottom) -> the texture (RGBA bytes, row 0 = top)
 void rt_present_upload(u32 const *rgba8);

@@ -11,8 +11,10 @@ in a second or two, bit for bit, ids and traversal counters included, through BO
 builders; (ii) a crop of the frame at the STATED sample count, bit for bit; (iii)
 size-independent properties of the stated frame (sample counts, finiteness, no energy
 gain, rank partition == single-GPU frame, rays of the ranks add up, rerun identical).
-All ranks run on the one GPU of the box; RCCL itself is covered by tests/test_group.py
-(one-rank communicator) and the world-2 gloo test."""
+All ranks run on the one GPU of the box.  What runs of RCCL there is the one-rank communicator of
+tests/test_group.py::test_one_rank_communicator_moves_the_tiles_through_rccl (binding, signatures,
+stream ordering of a grouped send / receive to self); the exchange between DIFFERENT GPUs has not
+run anywhere yet.  The N > 1 host logic is covered by the world-2 gloo test on CPU."""
 import numpy as np
 import pytest
 

@@ -3,8 +3,9 @@
 
 A one-device group runs the real pipeline (worker thread, two streams, compact tiles, untile,
 resolve); a group that lists device 0 several times rehearses N ranks on one GPU (RCCL refuses
-a device twice, so the tile buffers then move by device copies - the RCCL exchange itself needs
-N real GPUs and is exercised by the driver's multi-GPU run and by `rt_headless --gpus N`).
+a device twice, so the tile buffers then move by device copies; the RCCL exchange between DIFFERENT
+GPUs needs N real GPUs and has run nowhere yet - what a one-GPU box can run of it is the one-rank
+communicator of test_one_rank_communicator_moves_the_tiles_through_rccl).
 Every frame must equal the one-context frame / the oracle bit for bit."""
 import numpy as np
 import pytest
@@ -130,3 +131,97 @@ def test_render_resolved_keeps_the_accumulation_on_the_gpu(ra, oracle, gpu_ctx):
     gpu_ctx.upload(scene)                                        # an upload drops the resident sum
     with pytest.raises(ra.RtgpuError, match="resident"):
         gpu_ctx.resident_accum(w, h)
+
+
+@pytest.mark.parametrize("device_side", [False, True])
+def test_refit_restarts_the_resident_accumulation(ra, oracle, gpu_ctx, device_side):
+    """include/rtgpu.h: after a refit the rtgpu_render_resolved sum starts again - a progressive loop
+    that keeps RTGPU_FLAG_ACCUMULATE across a refit must not add samples of the new geometry onto the
+    sum of the old one (ghosting)."""
+    import torch
+    w, h = 160, 96
+    scene, cam = ra.Scene.builtin(0, aspect=w / h)
+    gpu_ctx.upload(scene)
+    st = ra.default_settings(w, h, spp=2, max_depth=6, flags=ra.FLAG_ACCUMULATE)
+    gpu_ctx.render_resolved(cam, st)
+    gpu_ctx.render_resolved(cam, st)                             # two frames of the old geometry in the sum
+    moved = ra.Scene(scene.spheres.copy(), scene.triangles.copy(), scene.materials.copy())
+    moved.spheres["center"][1:, 1] += 0.35                       # every small sphere hops
+    if device_side:
+        ds = torch.from_numpy(moved.spheres.view(np.uint8).copy()).cuda()
+        dt = torch.from_numpy(moved.triangles.view(np.uint8).copy()).cuda()
+        gpu_ctx.refit_device(ds.data_ptr(), len(moved.spheres), dt.data_ptr(), len(moved.triangles))
+    else:
+        gpu_ctx.refit(moved)
+    with pytest.raises(ra.RtgpuError, match="resident"):
+        gpu_ctx.resident_accum(w, h)
+    rgba, _ = gpu_ctx.render_resolved(cam, st)                   # flag still set: must be a fresh frame
+    st_o = st.copy()
+    st_o.flags = 0
+    fresh, _, _ = oracle.render(gpu_ctx.flat_scene().c, cam, st_o, threads=8)
+    assert np.array_equal(rgba, oracle.resolve(fresh))
+    assert_bit_equal(gpu_ctx.resident_accum(w, h), fresh, "sum after the refit")
+
+
+def test_group_survives_a_refused_frame_and_breaks_cleanly(ra, gpu_ctx, monkeypatch):
+    """A frame every GPU refuses before its trace leaves nothing queued: the next frame works.  A failure in
+    the exchange step (injected) leaves the group unusable, says so, and rtgpu_group_destroy returns."""
+    w, h = 128, 64
+    scene, cam = ra.Scene.builtin(0, aspect=w / h)
+    gpu_ctx.upload(scene)
+    st = ra.default_settings(w, h, spp=2, max_depth=4, tile_size=16)
+    want, _, _ = gpu_ctx.render(cam, st)
+    g = ra.Group([0, 0, 0])
+    try:
+        g.upload(scene)
+        bad = st.copy()
+        bad.spp = 0
+        for _ in range(3):                                       # more refusals than frames may be in flight
+            with pytest.raises(ra.RtgpuError, match="spp"):
+                g.render_begin(cam, bad)
+        acc, _, _ = g.render(cam, st)
+        assert_bit_equal(acc, want, "frame after refused frames")
+    finally:
+        g.close()
+    monkeypatch.setenv("RTGPU_GROUP_DEBUG_FAIL_EXCHANGE", "1")
+    g = ra.Group([0, 0, 0])
+    try:
+        g.upload(scene)
+        with pytest.raises(ra.RtgpuError, match="injected.*unusable"):
+            g.render_begin(cam, st)
+        with pytest.raises(ra.RtgpuError, match="unusable"):
+            g.render_begin(cam, st)
+        with pytest.raises(ra.RtgpuError, match="unusable"):
+            g.upload(scene)
+    finally:
+        g.close()                                                # must not hang
+    monkeypatch.delenv("RTGPU_GROUP_DEBUG_FAIL_EXCHANGE")
+    acc, _, _ = gpu_ctx.render(cam, st)                          # the GPU is fine afterwards
+    assert_bit_equal(acc, want, "context after a broken group")
+
+
+def test_one_rank_communicator_moves_the_tiles_through_rccl(ra, gpu_ctx, monkeypatch):
+    """RTGPU_GROUP_SELF_RCCL=1: a one-device group makes a one-rank communicator (ncclCommInitAll) and its
+    tile buffer travels by a grouped ncclSend / ncclRecv to itself on the exchange stream.  This is the part
+    of the N-GPU wire a one-GPU box can run: dlopen of librccl, the symbol table, the call signatures and the
+    stream ordering around the exchange.  Two frames in flight."""
+    monkeypatch.setenv("RTGPU_GROUP_SELF_RCCL", "1")
+    w, h = 200, 120
+    scene, cam = ra.Scene.builtin(0, aspect=w / h)
+    gpu_ctx.upload(scene)
+    sa = ra.default_settings(w, h, spp=3, max_depth=8, tile_size=32, seed=5, flags=ra.FLAG_STATS)
+    sb = ra.default_settings(w, h, spp=2, max_depth=8, tile_size=32, seed=6, flags=ra.FLAG_STATS)
+    g = ra.Group([0])
+    try:
+        g.upload(scene)
+        g.render_begin(cam, sa)
+        g.render_begin(cam, sb)
+        fa, _, st_a = g.render_end()
+        fb, _, st_b = g.render_end()
+        wa, _, wst_a = gpu_ctx.render(cam, sa)
+        wb, _, wst_b = gpu_ctx.render(cam, sb)
+        assert_bit_equal(fa, wa, "frame A through RCCL")
+        assert_bit_equal(fb, wb, "frame B through RCCL")
+        assert st_a.as_dict() == wst_a.as_dict() and st_b.as_dict() == wst_b.as_dict()
+    finally:
+        g.close()
