@@ -9,11 +9,18 @@ A "step" is one pass of the trace loop over one frame.
   --config c4 (default at N>1)  BASELINE.json configs[3]: S0, 3840x2160, 256 spp in total, depth 8,
                                 the frame split into 16x16 tiles interleaved over the N ranks:
                                 strong scaling.  (At N=1 it is the same frame on one GPU.)
+  --config c5                   BASELINE.json configs[4]: S2 level 8 (10,485,760 triangles), 1920x1080,
+                                16 spp per frame, depth 8, split over the N ranks: strong scaling.
 
-One process per GPU; every rank traces its tiles from a replicated scene into a compact tile
-buffer, RCCL gathers the buffers to rank 0 (each peer straight to the root) and rank 0
-de-interleaves them.  The gather of frame k overlaps the trace of frame k+1 (two compact
-buffers; the collective runs on RCCL's stream).
+Every rank traces its tiles from a replicated scene into a compact tile buffer, the buffers are
+gathered to rank 0 (each peer straight to the root) and rank 0 de-interleaves them; the gather
+of frame k overlaps the trace of frame k+1.  Two hosts for that path:
+  * launched by torch.distributed.run (WORLD_SIZE set; what the driver does for N > 1): one
+    process per GPU, `dist.gather` over backend nccl = RCCL;
+  * plain `python3 bench.py --gpus N` (no launcher): --transport group (default) renders through
+    the native rtgpu_group_* in THIS process (one worker thread per GPU, ncclCommInitAll,
+    ncclSend / ncclRecv - SURVEY.md §8e as written); --transport procs starts N fresh child
+    processes under torch.distributed.run and relays rank 0's line (the parent never touches a GPU).
 
 Prints ONE JSON line (rank 0).  `value` = rays (segments: primary + every bounce, counted by the
 kernel) traced by all ranks per second of wall time, inputs and outputs resident in HBM.
@@ -24,13 +31,16 @@ tree is served from LDS - as counted flops / kernel time against the 157.3 TFLOP
 wave64 VALU instruction per SIMD per 2 cycles at 2.4 GHz; measured: tools/ubench/valu_issue.hip,
 profiles/r02/ubench_valu_issue.txt), `roofline.hbm` the memory side (measured traffic from the
 committed PMC passes of the same workload; algorithmic bytes for information).  At N=1 the
-`also` array carries C3 (S1, 1.31 M triangles, 1080p, 64 spp: HBM/L2-bound by §8d) and C4's frame
-on one GPU, measured outside the timed region.  `cpu_baseline` is the CPU oracle
-(oracle/rt_oracle.c) on a bounded sample.
+`also` array carries C3 (S1, 1.31 M triangles, 1080p, 64 spp: HBM/L2-bound by §8d), C4's frame and
+C5's frame (S2 level 8, 10.5 M triangles, 1080p, 16 spp) on one GPU, measured outside the timed
+region, each beside its own `cpu_baseline`.  `cpu_baseline` is the CPU oracle (oracle/rt_oracle.c)
+on a bounded sample of the same workload: the same scene, frame size and depth at a reduced
+sample count - the oracle's rate is flat in spp (every sample is an independent path).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -113,37 +123,39 @@ def roofline_block(bound, counts, n_px, node_bytes, k_ms, kernel, pmc, ub):
     return out
 
 
-def cpu_baseline(width, height, depth, sample_spp):
-    """CPU oracle on the box's host cores: the SAME scene/resolution/depth at
-    `sample_spp` samples per pixel (a bounded sample of the 16-spp frame)."""
+def cpu_baseline(flat_c, cam, label, width, height, depth, sample_spp, frame_spp, one_core=True):
+    """CPU oracle on the box's host cores over the flattened scene the GPU traverses: the SAME
+    scene / frame size / depth at `sample_spp` of the frame's `frame_spp` samples per pixel (a
+    bounded sample; the rate is flat in spp: samples are independent paths of equal expected cost)."""
     import rt_amd as ra
     from oracle import Oracle
 
     cores = min(len(os.sched_getaffinity(0)), 16)
-    scene, cam = ra.Scene.builtin(0, aspect=width / height)
-    fs = ra.FlatScene.build(scene)
     st = ra.default_settings(width, height, spp=sample_spp, max_depth=depth)
     o = Oracle()
     t0 = time.perf_counter()
-    _, _, stats = o.render(fs.c, cam, st, threads=cores, want_ids=False)
+    _, _, stats = o.render(flat_c, cam, st, threads=cores, want_ids=False)
     dt = time.perf_counter() - t0
-    # the reference program is single-threaded by design (SURVEY.md §8d): one core, 1 spp
-    st1 = ra.default_settings(width, height, spp=1, max_depth=depth)
-    t0 = time.perf_counter()
-    _, _, stats1 = o.render(fs.c, cam, st1, threads=1, want_ids=False)
-    dt1 = time.perf_counter() - t0
-    return {
+    out = {
         "value": round(stats["rays"] / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
-        "sample": f"S0 {width}x{height}, {sample_spp} of the frame's spp, depth {depth}: "
-                  f"{stats['rays']} rays in {dt:.2f} s (OpenMP over rows)",
-        "one_core": {"value": round(stats1["rays"] / dt1 / 1e6, 3), "unit": "Mrays/s", "cores": 1,
-                     "sample": f"1 spp of the same frame: {stats1['rays']} rays in {dt1:.2f} s"},
+        "sample": f"{label} {width}x{height}, {sample_spp} of the frame's {frame_spp} spp, depth {depth}: "
+                  f"{stats['rays']} rays in {dt:.2f} s (OpenMP over rows; rate flat in spp)",
     }
+    if one_core:
+        # the reference program is single-threaded by design (SURVEY.md §8d): one core, 1 spp
+        st1 = ra.default_settings(width, height, spp=1, max_depth=depth)
+        t0 = time.perf_counter()
+        _, _, stats1 = o.render(flat_c, cam, st1, threads=1, want_ids=False)
+        dt1 = time.perf_counter() - t0
+        out["one_core"] = {"value": round(stats1["rays"] / dt1 / 1e6, 3), "unit": "Mrays/s", "cores": 1,
+                           "sample": f"1 spp of the same frame: {stats1['rays']} rays in {dt1:.2f} s"}
+    return out
 
 
-def also_workload(ra, torch, ctx, dev, name, label, kind, param, w, h, spp, depth, bound, reps):
+def also_workload(ra, torch, ctx, dev, name, label, kind, param, w, h, spp, depth, bound, reps, cpu_spp):
     """One more workload on this GPU, outside the timed region: `reps` frames after one
-    instrumented frame (counts) that doubles as the warm-up."""
+    instrumented frame (counts) that doubles as the warm-up; then the CPU oracle on `cpu_spp`
+    samples per pixel of the same frame (0 = skip)."""
     scene, cam = ra.Scene.builtin(kind, param=param, aspect=w / h)
     ctx.upload(scene)
     acc = torch.zeros((h * w, 4), dtype=torch.float32, device=dev)
@@ -163,29 +175,177 @@ def also_workload(ra, torch, ctx, dev, name, label, kind, param, w, h, spp, dept
     k_ms = sum(ms) / len(ms)
     pmc, ub = committed_pmc(name, w, h, spp, depth)
     del acc
-    return {"workload": label + f" ({scene.n_prims} prims), {w}x{h}, {spp} spp, depth {depth}, one GPU",
-            "ms": round(wall_ms, 3), "frames": reps, "rays_per_frame": counts["rays"],
-            "mrays_per_s": round(counts["rays"] / (wall_ms * 1e-3) / 1e6, 1),
-            "roofline": roofline_block(bound, counts, w * h, node_bytes_of(ctx), k_ms, ctx.kernel_name(), pmc, ub)}
+    out = {"workload": label + f" ({scene.n_prims} prims), {w}x{h}, {spp} spp, depth {depth}, one GPU",
+           "ms": round(wall_ms, 3), "frames": reps, "rays_per_frame": counts["rays"],
+           "mrays_per_s": round(counts["rays"] / (wall_ms * 1e-3) / 1e6, 1),
+           "roofline": roofline_block(bound, counts, w * h, node_bytes_of(ctx), k_ms, ctx.kernel_name(), pmc, ub)}
+    out["cpu_baseline"] = (cpu_baseline(ctx.flat_scene().c, cam, label.split(":")[0], w, h, depth, cpu_spp, spp, one_core=False)
+                           if cpu_spp > 0 else None)
+    return out
 
 
-def main():
+CONFIGS = {
+    # name: (scene kind, scene param, label, width, height, spp, scaling, bound, steps, warmup)
+    "c2": (0, 0, "C2: procedural scene S0 (RTIOW cover", 1920, 1080, 16, "weak", "valu", 20, 3),
+    "c4": (0, 0, "C4: procedural scene S0 (RTIOW cover", 3840, 2160, 256, "strong", "valu", 5, 1),
+    "c5": (2, 8, "C5: procedural soup S2 level 8 (8 displaced icospheres", 1920, 1080, 16, "strong", "hbm", 10, 2),
+}
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--config", choices=("c2", "c4"), default=None,
+    ap.add_argument("--config", choices=tuple(CONFIGS), default=None,
                     help="c2: 1080p, 16 spp per GPU (weak scaling over N); c4: 4K, 256 spp in total (strong scaling); "
-                         "default c2 at --gpus 1, c4 otherwise")
+                         "c5: 10.5 M triangles, 1080p, 16 spp in total (strong scaling); default c2 at --gpus 1, c4 otherwise")
+    ap.add_argument("--transport", choices=("group", "procs"), default="group",
+                    help="--gpus N > 1 WITHOUT a launcher: group = the native rtgpu_group in this process (one thread per GPU, "
+                         "RCCL send/recv); procs = N fresh child processes under torch.distributed.run.  Ignored when "
+                         "WORLD_SIZE is set (the launcher's per-process path)")
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
-    ap.add_argument("--spp", type=int, default=None, help="c2: samples per pixel PER GPU; c4: per frame")
+    ap.add_argument("--spp", type=int, default=None, help="c2: samples per pixel PER GPU; c4, c5: per frame")
     ap.add_argument("--depth", type=int, default=8)
-    ap.add_argument("--cpu-spp", type=int, default=16, help="spp of the cpu_baseline sample (0 = skip)")
-    ap.add_argument("--no-also", action="store_true", help="skip the C3 / C4-frame measurements of the `also` array")
-    args = ap.parse_args()
+    ap.add_argument("--builder", choices=("sah", "lbvh"), default="sah", help="BVH builder (lbvh: on the GPU)")
+    ap.add_argument("--cpu-spp", type=int, default=16, help="spp of the cpu_baseline sample of the timed workload (0 = skip all CPU baselines)")
+    ap.add_argument("--no-also", action="store_true", help="skip the C3 / C4-frame / C5-frame measurements of the `also` array")
+    return ap.parse_args()
 
+
+def resolve_config(args, world):
+    config = args.config or ("c2" if world == 1 else "c4")
+    kind, param, label, w0, h0, spp0, scaling, bound, steps0, warm0 = CONFIGS[config]
+    W, H = args.width or w0, args.height or h0
+    spp_arg = args.spp or spp0
+    spp = spp_arg * world if config == "c2" else spp_arg   # c2: per-GPU work fixed; c4, c5: the frame is fixed
+    steps = args.steps or steps0
+    warmup = warm0 if args.warmup is None else args.warmup
+    return config, kind, param, label, W, H, spp_arg, spp, scaling, bound, steps, warmup
+
+
+def workload_text(config, label, n_prims, W, H, spp_arg, spp, depth, tile, world, how):
+    return (f"{label}, {n_prims} prims), {W}x{H}, "
+            + (f"{spp_arg} spp per GPU ({spp} spp total)" if config == "c2" else f"{spp} spp per frame (split over the ranks)")
+            + f", depth {depth}, pinhole, {tile}x{tile} tiles interleaved over {world} GPU(s)" + how)
+
+
+def estimate_for_rank(pmc, world):
+    """N > 1: no PMC pass of a rank's compact launch is committed; what the single-GPU pass of the whole
+    frame implies for one rank (1/N of its tiles) is reported as an ESTIMATE under its own key, never as
+    `traffic` / `hbm.measured_gbs` / `valu_issue`."""
+    if not pmc:
+        return None
+    return {"estimated": True, "model": f"1/{world} of the single-GPU launch of the whole frame",
+            "traffic_bytes_per_launch": pmc["traffic_bytes_per_launch"] / world,
+            "valu_insts_per_launch": pmc.get("valu_insts_per_launch", 0) / world or None,
+            "source": pmc.get("source")}
+
+
+def self_launch(args):
+    """--gpus N > 1, no launcher, --transport procs: N fresh children under torch.distributed.run; this
+    process never touches a GPU (a process that has initialised the GPU must not be replaced, and is not:
+    the children are started, not exec'ed) and relays rank 0's JSON line and the children's exit code."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    if r.returncode != 0 or len(lines) != 1:
+        sys.stdout.write(r.stdout)
+        raise SystemExit(f"bench.py: the {args.gpus} child ranks failed (exit code {r.returncode}, {len(lines)} result lines)")
+    print(lines[0], flush=True)
+
+
+def need_gpus(torch, n, share_gpu):
+    have = torch.cuda.device_count()   # counting devices does not initialise the GPU
+    want = 1 if share_gpu else n
+    if have < want:
+        raise SystemExit(f"bench.py --gpus {n} needs {want} GPU(s), this machine has {have} (no CPU fallback exists)")
+
+
+def run_group(args, torch, ra, share_gpu):
+    """--gpus N > 1 in ONE process: the native group (rt_amd/csrc/group.cpp), frames pipelined two deep."""
+    world = args.gpus
+    config, kind, param, label, W, H, spp_arg, spp, scaling, bound, steps, warmup = resolve_config(args, world)
+    depth, tile = args.depth, 16
+    devices = [0] * world if share_gpu else list(range(world))
+    g = ra.Group(devices)
+    scene, cam = ra.Scene.builtin(kind, param=param, aspect=W / H)
+    g.upload(scene, builder=args.builder)
+    st = ra.default_settings(W, H, spp=spp, max_depth=depth, tile_size=tile)
+    st_stats = st.copy()
+    st_stats.flags |= ra.FLAG_STATS
+    _, _, stats = g.render(cam, st_stats, want_accum=False, want_rgba8=False)   # counts for the roofline, untimed
+    counts = stats.as_dict()
+
+    def sync():
+        for d in set(devices):
+            torch.cuda.synchronize(d)
+
+    def frames(n):
+        rays = 0
+        for k in range(n + 1):
+            if k < n:
+                g.render_begin(cam, st)          # frame k+1 is queued before frame k is collected
+            if k > 0:
+                rays += g.render_end(want_accum=False, want_rgba8=False)[2].rays
+        return rays
+
+    frames(warmup)
+    sync()
+    t0 = time.perf_counter()
+    rays = frames(steps)
+    sync()
+    dt = time.perf_counter() - t0
+    k_ms = max(g.kernel_ms(i) for i in range(world))
+    ranks = g.comm_ranks
+    g.close()
+    pmc, ub = committed_pmc(config, W, H, spp_arg, depth)
+    per_rank = {k: v // world for k, v in counts.items()}
+    node_bytes = 96 if kind != 0 else 64
+    roof = roofline_block(bound, per_rank, W * H // world, node_bytes, k_ms, "trace_kernel (slowest rank's last frame)", None, ub)
+    roof["estimated_from_single_gpu_pass"] = estimate_for_rank(pmc, world)
+    how = (f", native group: one process, {world} worker threads, "
+           + (f"RCCL communicator of {ranks} ranks (ncclCommInitAll), ncclSend / ncclRecv to GPU {devices[0]}" if ranks
+              else "tile buffers moved by device copies")
+           + ", gather overlapped with the next frame's trace"
+           + (" [REHEARSAL: all ranks on GPU 0, no RCCL]" if share_gpu else ""))
+    ms_step = dt / steps * 1e3
+    out = {
+        "metric": "Mrays/s (whole job)", "value": round(rays / dt / 1e6, 2), "unit": "Mrays/s", "n_gpus": world,
+        "steps": steps, "warmup": warmup, "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": scaling,
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": workload_text(config, label, scene.n_prims, W, H, spp_arg, spp, depth, tile, world, how),
+                   "transport": "group", "rccl_ranks": ranks, "rays_per_step": rays // steps, "paths_per_step": W * H * spp,
+                   "mrays_per_s_per_gpu": round(rays / dt / 1e6 / world, 2), "ms_per_frame_1080p_16spp": None},
+        "roofline": roof, "cpu_baseline": None,
+    }
+    print(json.dumps(out), flush=True)
+
+
+def main():
+    args = parse_args()
+    launched = "WORLD_SIZE" in os.environ
+    share_gpu = os.environ.get("RT_BENCH_SHARE_GPU") == "1"
+    # RT_BENCH_SHARE_GPU=1 is a REHEARSAL mode for a one-GPU box: every rank uses GPU 0 and the gather
+    # goes through gloo on host copies (procs) or device copies (group).  Never used by the driver; the
+    # JSON says so in config.workload.
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
     import torch
+    if not launched and args.gpus > 1:
+        need_gpus(torch, args.gpus, share_gpu)
+        if args.transport == "procs":
+            return self_launch(args)
+        import rt_amd as ra
+        return run_group(args, torch, ra, share_gpu)
+
     import torch.distributed as dist
 
     import rt_amd as ra
@@ -194,13 +354,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher set WORLD_SIZE={world}")
+    need_gpus(torch, world, share_gpu)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
-    # RT_BENCH_SHARE_GPU=1 is a REHEARSAL mode for a one-GPU box: every rank uses
-    # GPU 0 and the gather goes through gloo on host copies.  Never used by the
-    # driver; the JSON says so in config.workload.
-    share_gpu = os.environ.get("RT_BENCH_SHARE_GPU") == "1"
     if share_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -212,27 +369,15 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    config = args.config or ("c2" if world == 1 else "c4")
+    config, kind, param, label, W, H, spp_arg, spp, scaling, bound, steps, warmup = resolve_config(args, world)
     depth = args.depth
-    if config == "c2":
-        W, H = args.width or 1920, args.height or 1080
-        spp_arg = args.spp or 16
-        spp = spp_arg * world                      # per-GPU work fixed
-        scaling = "weak"
-        steps, warmup = args.steps or 20, 3 if args.warmup is None else args.warmup
-    else:
-        W, H = args.width or 3840, args.height or 2160
-        spp_arg = args.spp or 256
-        spp = spp_arg                              # the frame is fixed, the ranks split it
-        scaling = "strong"
-        steps, warmup = args.steps or 5, 1 if args.warmup is None else args.warmup
     # 16x16 tiles: the slowest of 8 ranks is then 0.8 % above the mean (64x64: 4.2 %, 32x32:
     # 1.3 %; tools/gpu_rank_balance.py), and every rank owns the same number of tiles.  The
     # image does not depend on the tile size.
     tile = 16
     ctx = ra.Context(local_rank)
-    scene, cam = ra.Scene.builtin(0, aspect=W / H)
-    ctx.upload(scene)
+    scene, cam = ra.Scene.builtin(kind, param=param, aspect=W / H)
+    ctx.upload(scene, builder=args.builder)
 
     compact = world > 1
     flags = ra.FLAG_COMPACT if compact else 0
@@ -324,43 +469,44 @@ def main():
         k_ms = sum(kernel_ms) / len(kernel_ms)
         n_px_rank = counts["paths"] // spp
         pmc, ub = committed_pmc(config, W, H, spp_arg, depth)
-        if world > 1 and pmc and config == "c4":
-            # rank 0's launch: its 1/N share of the tiles of the frame whose single-GPU launch the PMC passes measured
-            # (the traffic is the chunk planes and sums of the rank's own pixels; the scene is read once per block)
-            pmc = dict(pmc)
-            for k in ("traffic_bytes_per_launch", "valu_insts_per_launch", "fetch_size_kib", "write_size_kib"):
-                if pmc.get(k) is not None:
-                    pmc[k] = pmc[k] / world
-            pmc["source"] = f"1/{world} of: " + pmc.get("source", "")
-        elif world > 1:
-            pmc = None
         ms_step = dt / steps * 1e3
-        name = "C2" if config == "c2" else "C4"
+        how = ""
+        if compact:
+            how = (f", one process per GPU, torch.distributed gather to rank 0 over "
+                   + ("gloo via host copies [REHEARSAL: all ranks on one GPU]" if share_gpu
+                      else f"backend nccl (RCCL communicator of {dist.get_world_size()} ranks)")
+                   + ", overlapped with the next frame's trace")
+        roof = roofline_block(bound, counts, n_px_rank, node_bytes_of(ctx), k_ms, ctx.kernel_name(), pmc if world == 1 else None, ub)
+        if world > 1:
+            roof["estimated_from_single_gpu_pass"] = estimate_for_rank(pmc, world)
         out = {
             "metric": "Mrays/s (whole job)", "value": round(rays_per_step * steps / dt / 1e6, 2),
             "unit": "Mrays/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": round(ms_step, 4), "higher_is_better": True,
             "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": f"{name}: procedural scene S0 (RTIOW cover, {scene.n_prims} prims), {W}x{H}, "
-                            + (f"{spp_arg} spp per GPU ({spp} spp total)" if config == "c2" else f"{spp} spp per frame (split over the ranks)")
-                            + f", depth {depth}, pinhole, {tile}x{tile} tiles interleaved over {world} GPU(s)"
-                            + (", RCCL gather to rank 0 overlapped with the next frame's trace" if compact and not share_gpu else "")
-                            + (" [REHEARSAL: all ranks on one GPU, gloo gather via host]" if share_gpu else ""),
+                "workload": workload_text(config, label, scene.n_prims, W, H, spp_arg, spp, depth, tile, world, how),
+                "transport": "procs" if compact else None,
+                "rccl_ranks": (0 if share_gpu else dist.get_world_size()) if compact else None,
                 "rays_per_step": int(rays_per_step), "paths_per_step": W * H * spp,
                 "mrays_per_s_per_gpu": round(rays_per_step * steps / dt / 1e6 / world, 2),
                 "ms_per_frame_1080p_16spp": round(ms_step, 4) if (world == 1 and config == "c2" and (W, H, spp) == (1920, 1080, 16)) else None,
             },
-            "roofline": roofline_block("valu", counts, n_px_rank, node_bytes_of(ctx), k_ms, ctx.kernel_name(), pmc, ub),
+            "roofline": roof,
         }
         if args.cpu_spp > 0 and world == 1:
-            out["cpu_baseline"] = cpu_baseline(1920, 1080, depth, args.cpu_spp)
+            sample = args.cpu_spp if config != "c5" else min(args.cpu_spp, 2)
+            out["cpu_baseline"] = cpu_baseline(ctx.flat_scene().c, cam, config.upper(), W, H, depth, min(sample, spp), spp)
         else:
             out["cpu_baseline"] = None
         if world == 1 and not args.no_also:
-            also = [also_workload(ra, torch, ctx, dev, "c3", "C3: procedural mesh S1 level 8", 1, 8, 1920, 1080, 64, 8, "hbm", 3)]
+            cpu = args.cpu_spp > 0
+            also = []
+            if config != "c5":  # (the timed workload itself otherwise)
+                also.append(also_workload(ra, torch, ctx, dev, "c5", "C5: procedural soup S2 level 8", 2, 8, 1920, 1080, 16, 8, "hbm", 3, 2 if cpu else 0))
+            also.append(also_workload(ra, torch, ctx, dev, "c3", "C3: procedural mesh S1 level 8", 1, 8, 1920, 1080, 64, 8, "hbm", 3, 4 if cpu else 0))
             if config == "c2":
-                also.append(also_workload(ra, torch, ctx, dev, "c4", "C4's frame: S0", 0, 0, 3840, 2160, 256, 8, "valu", 2))
+                also.append(also_workload(ra, torch, ctx, dev, "c4", "C4's frame: S0", 0, 0, 3840, 2160, 256, 8, "valu", 2, 2 if cpu else 0))
             out["also"] = also
         print(json.dumps(out), flush=True)
     if world > 1:
