@@ -1186,9 +1186,18 @@ void trace_kernel(const KParams P) {
                 const f4 a = tri_cache[j3], b = tri_cache[j3 + 1u], c = tri_cache[j3 + 2u];
                 rec[k][0] = make_float4(a.x, a.y, a.z, a.w); rec[k][1] = make_float4(b.x, b.y, b.z, b.w);
                 rec[k][2] = make_float4(c.x, c.y, c.z, c.w);
+              } else if (k == 0) {
+                rec[0][0] = tp[0]; rec[0][1] = tp[1]; rec[0][2] = tp[2];
               } else {
-                const float4 *tq = tp + 3u * ((uint32_t)k < more ? (uint32_t)k : more);
-                rec[k][0] = tq[0]; rec[k][1] = tq[1]; rec[k][2] = tq[2];
+                // Only lanes that HAVE a k-th triangle left request it: the vector memory pipeline charges a load by
+                // its active lanes (~0.7 cycle per lane and 16 bytes, tools/ubench/l1_td.hip), and on a fine mesh most
+                // leaves hold one triangle - re-reading the last record in the other lanes (what this did before)
+                // was a tenth of all the lane-loads of the S1 frame.  The loads of all k are still in flight together.
+                rec[k][0] = rec[k][1] = rec[k][2] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if ((uint32_t)k <= more) {
+                  const float4 *tq = tp + 3u * (uint32_t)k;
+                  rec[k][0] = tq[0]; rec[k][1] = tq[1]; rec[k][2] = tq[2];
+                }
               }
             }
             if (STATS) n_tris += 1u + more;

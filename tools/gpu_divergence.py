@@ -26,6 +26,9 @@ for name in sys.argv[1:] or ["c2", "c3", "c5"]:
           + f" cycles per node step {c[21] / max(1, w_node):.0f}, per leaf step {c[22] / max(1, w_sph + w_tri):.0f})"
           + f"\n   lanes still traversing per node step {c[26] / max(1, w_node):.1f} (of them at a node {nodes / max(1, c[26]):.3f}), "
             f"per leaf step {c[27] / max(1, w_sph + w_tri):.1f} (of them tested {(sphs + tris) / max(1, c[27]):.3f})"
+          + f"\n   shader-clock ticks of a wave per outer iteration: " + " ".join(f"{n}={v / max(1, w_outer):.0f}" for n, v in
+                                           zip(("shade", "item", "gen", "setup", "traversal"), cyc))
+          + f"; per wave in all {sum(cyc) / 4096:.0f} ticks for a {ctx.kernel_ms():.3f} ms kernel = {sum(cyc) / 4096 / ctx.kernel_ms() / 1e3:.0f} ticks per microsecond"
           + (f"\n   {ctx.kernel_name()}: node-step lanes served from the LDS copy of the top {c[24] / max(1, c[23]):.3f}, "
              f"node steps on the slow stack path {c[25] / max(1, w_node):.4f}" if c[23] else "")
           + (f"\n   {ctx.kernel_name()}: slot exchanges per 64 rays {c[28] * 64 / rays:.2f}, lanes per exchange {c[29] / max(1, c[28]):.1f}"
