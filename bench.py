@@ -99,9 +99,27 @@ def roofline_block(bound, counts, n_px, node_bytes, k_ms, kernel, pmc, ub):
            "note": "measured = FETCH_SIZE + WRITE_SIZE of the committed PMC passes of this workload / this run's kernel "
                    "time; algorithmic = every node / primitive / material fetch a ray makes, most of them served by "
                    "LDS, L1 and L2 - informational, never a fraction of HBM"}
+    vmem = None
+    caps = ub.get("vmem_records_per_cycle_per_cu") or {}
+    if node_bytes != 64 and caps.get("node96_l2") and caps.get("tri48_l2"):
+        # Trees in memory: what the vector memory pipeline (TA / L1) can deliver for THIS access pattern - every lane its own
+        # record, 16 bytes per lane and load.  tools/ubench/node_fetch.hip measures records per cycle per CU by record shape;
+        # the floor of the launch is its node visits and triangle tests at those rates (tables that fit one L2: an upper
+        # bound on the rate, since part of the real fetches miss L2).
+        cus, clk = 256, 2.4e9
+        node_cap = caps["node96_l2"] if node_bytes == 96 else caps.get("tri48_l2")   # packed 48-byte BVH2 nodes fetch like triangles
+        floor_s = (counts["nodes"] / node_cap + counts["tri_tests"] / caps["tri48_l2"]) / cus / clk
+        vmem = {"records_per_launch": counts["nodes"] + counts["tri_tests"],
+                "achieved_records_per_cycle_per_cu": round((counts["nodes"] + counts["tri_tests"]) / (sec * clk * cus), 4),
+                "peak_node_records_per_cycle_per_cu": node_cap, "peak_triangle_records_per_cycle_per_cu": caps["tri48_l2"],
+                "floor_ms": round(floor_s * 1e3, 3), "frac": round(floor_s / sec, 3), "source": ub.get("vmem_source"),
+                "note": "the bound that binds these scenes: one random record per lane and step through the vector L1 (16 B per lane "
+                        "and load; ~0.7 cycle per lane-load).  frac = time the launch's record fetches need at the measured peak rate / "
+                        "kernel time.  The HBM fraction above is what the contract's `bound` asks for; this is the roofline the kernel "
+                        "actually runs against (DESIGN.md §5.2)."}
     out = {"bound": bound, "traffic": traffic, "traffic_source": pmc.get("source") if pmc else None,
            "kernel": kernel, "kernel_ms": round(k_ms, 4),
-           "kernel_mrays_per_s": round(counts["rays"] / sec / 1e6, 1), "valu": valu, "hbm": hbm}
+           "kernel_mrays_per_s": round(counts["rays"] / sec / 1e6, 1), "valu": valu, "hbm": hbm, "vmem": vmem}
     if bound == "valu":
         out.update({"achieved": valu["achieved_tflops"], "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": valu["frac"]})
     else:

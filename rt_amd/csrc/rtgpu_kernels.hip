@@ -50,6 +50,10 @@ namespace {
 #endif
 constexpr int      kTriStep    = RTGPU_TRI_STEP;   // triangles a lane tests per leaf step (trees outside LDS)
 constexpr int      kBlock      = RTGPU_KBLOCK;
+#ifndef RTGPU_KBLOCK2
+#define RTGPU_KBLOCK2 768
+#endif
+constexpr int      kBlock2     = RTGPU_KBLOCK2;    // threads per block of MODE 8 (two rays per lane): 12 waves, three per SIMD
 constexpr int      kBlocksPerCU = RTGPU_BLOCKS_PER_CU; // one block per CU: 16 waves share one LDS copy of the top of the BVH
 constexpr int      kStackLds   = 32;   // most entries per lane the LDS stack may get (4 KiB per entry per block)
 constexpr int      kLdsBytes   = 160 * 1024 / kBlocksPerCU - (kBlocksPerCU > 1 ? 2048 : 0);  // LDS per CU on gfx950, shared equally by the CU's blocks
@@ -61,22 +65,11 @@ constexpr uint32_t kDone       = 0xFFFFFFFFu;  // == RTGPU_REF_EMPTY, has the le
 #define RTGPU_SMALL_NODES (RTGPU_BLOCKS_PER_CU == 1 ? 1365 : 512)
 #endif
 constexpr int      kSmallNodes = RTGPU_SMALL_NODES;
-// MODE 8 (two work items per lane, an experiment): a shading pass for the second slots runs while this many lanes
-// hold a result there; lanes exchange their slots mid-round from this many up; the round ends below this many
 #ifndef RTGPU_NODE_UNROLL  // node steps per vote on the scenes in LDS: the vote is 4 of a step's ~45 instructions (1 / 2 / 3 / 4: C4 206.8 / 204.4 / 207.0 / 209.1 ms)
 #define RTGPU_NODE_UNROLL 2
 #endif
 #ifndef RTGPU_PRIO_SMALL
 #define RTGPU_PRIO_SMALL 1
-#endif
-#ifndef RTGPU_DUAL_PASS_MIN
-#define RTGPU_DUAL_PASS_MIN 24
-#endif
-#ifndef RTGPU_DUAL_SWAP_MIN
-#define RTGPU_DUAL_SWAP_MIN 8
-#endif
-#ifndef RTGPU_DUAL_REFILL
-#define RTGPU_DUAL_REFILL 16
 #endif
 // MODE 7 of the trace kernel: a scene small enough to sit in LDS WHOLE - tree (planes kTinyNodes apart), leaf-ordered
 // spheres, triangles, and per PRIMITIVE what shading needs: the triangle's unit normal and id, the sphere's id and
@@ -263,7 +256,7 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 }
 
 // Traversal stack: up to kStackLds entries per lane in LDS, laid out
-// [entry][thread] (lane-consecutive dwords: conflict-free ds_read/ds_write_b32);
+// [entry][ray of the lane][thread] (lane-consecutive dwords: conflict-free ds_read/ds_write_b32);
 // deeper entries go to a per-lane slice of a global overflow buffer laid out the
 // same way.  Entry 0 holds the sentinel kDone, so a pop needs no emptiness test:
 // popping the sentinel ends the traversal.  A stack never grows past the tree
@@ -271,7 +264,8 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 // LDS_ONLY instantiation, whose node step has no branch at all - the far child
 // is always written above the top (kept only if both children were hit) and the
 // top is always read (used only if neither was).
-template <bool LDS_ONLY>
+// STRIDE: words between consecutive entries of one stack (the threads of the block x the rays a lane traverses).
+template <bool LDS_ONLY, int STRIDE>
 struct Stack {
   uint32_t *lds;        // &lds_stack[tid]
   uint32_t *ovf;        // &ovf[global thread]
@@ -288,11 +282,11 @@ struct Stack {
     top_at = base_at;
   }
   __device__ __forceinline__ void store(int at, uint32_t v) {
-    if (LDS_ONLY || at < lds_entries) lds[at * kBlock] = v;
+    if (LDS_ONLY || at < lds_entries) lds[at * STRIDE] = v;
     else ovf[(size_t)(at - lds_entries) * ovf_stride] = v;
   }
   __device__ __forceinline__ uint32_t load(int at) {
-    if (LDS_ONLY || at < lds_entries) return lds[at * kBlock];
+    if (LDS_ONLY || at < lds_entries) return lds[at * STRIDE];
     return ovf[(size_t)(at - lds_entries) * ovf_stride];
   }
   // the entry a pop would return (LDS form), read at the START of a node step so that the
@@ -301,9 +295,9 @@ struct Stack {
   // node step: push `far_c` if both children were hit, pop if none was
   __device__ __forceinline__ uint32_t step(bool both, bool none, uint32_t near_c, uint32_t far_c, uint32_t top) {
     if (LDS_ONLY) {
-      // one address: top at [0] (read by peek()), free entry at [kBlock] (immediate offset)
-      top_at[kBlock] = far_c;
-      top_at += both ? kBlock : (none ? -kBlock : 0);
+      // one address: top at [0] (read by peek()), free entry at [STRIDE] (immediate offset)
+      top_at[STRIDE] = far_c;
+      top_at += both ? STRIDE : (none ? -STRIDE : 0);
       return none ? top : near_c;
     }
     if (both) { store(sp, far_c); sp++; }
@@ -315,10 +309,10 @@ struct Stack {
   // what lies above the new top is never read)
   __device__ __forceinline__ uint32_t step4(int n, uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3, uint32_t top) {
     if (LDS_ONLY) {
-      top_at[kBlock] = n == 4 ? r3 : (n == 3 ? r2 : r1);
-      top_at[2 * kBlock] = n == 4 ? r2 : r1;
-      top_at[3 * kBlock] = r1;
-      top_at += (n == 0 ? -1 : n - 1) * kBlock;
+      top_at[STRIDE] = n == 4 ? r3 : (n == 3 ? r2 : r1);
+      top_at[2 * STRIDE] = n == 4 ? r2 : r1;
+      top_at[3 * STRIDE] = r1;
+      top_at += (n == 0 ? -1 : n - 1) * STRIDE;
       return n == 0 ? top : r0;
     }
     if (n == 0) { sp--; return load(sp); }
@@ -334,15 +328,15 @@ struct Stack {
   __device__ __forceinline__ uint32_t peek_hybrid(bool &fast) const {
     fast = __ballot(sp + 3 > lds_entries) == 0ull;
     uint32_t top = 0u;
-    if (fast) top = base_at[(sp - 1) * kBlock];
+    if (fast) top = base_at[(sp - 1) * STRIDE];
     return top;
   }
   __device__ __forceinline__ uint32_t step4_hybrid(bool fast, int n, uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3, uint32_t top) {
     if (fast) {
-      lds_u32 *t = base_at + (sp - 1) * kBlock;
-      t[kBlock] = n == 4 ? r3 : (n == 3 ? r2 : r1);
-      t[2 * kBlock] = n == 4 ? r2 : r1;
-      t[3 * kBlock] = r1;
+      lds_u32 *t = base_at + (sp - 1) * STRIDE;
+      t[STRIDE] = n == 4 ? r3 : (n == 3 ? r2 : r1);
+      t[2 * STRIDE] = n == 4 ? r2 : r1;
+      t[3 * STRIDE] = r1;
       sp += n == 0 ? -1 : n - 1;
       return n == 0 ? top : r0;
     }
@@ -364,7 +358,7 @@ struct Stack {
   // leaf step: pop if the leaf is exhausted
   __device__ __forceinline__ uint32_t pop_if(bool doit, uint32_t top) {  // top = peek() at the start of the step
     if (LDS_ONLY) {
-      top_at -= doit ? kBlock : 0;
+      top_at -= doit ? STRIDE : 0;
       return top;
     }
     uint32_t v = kDone;
@@ -409,14 +403,25 @@ __device__ __forceinline__ void wave_tick(unsigned lane, unsigned long long &c) 
 // copy measured slower and is off unless RTGPU_WIDE_CACHE=1; the hybrid stack is what trees with a
 // stack bound above 40 entries run on).  7: as 2 for a scene that fits LDS WHOLE (kTiny* above):
 // spheres, triangles and per-primitive shading records behind the tree; S0 runs this.
-// 8, 9, 10: modes 7, 6, 5 with TWO work items per lane (RTGPU_DUAL=1): the measured-negative
-// experiment of row N1, profiles/r02/experiments.txt H and J.
+// 8: as 7 with TWO rays per lane traversed in lock step (R = 2 below) in blocks of kBlock2 threads:
+// every lane owns two work items, each with its own traversal stack; a traversal step requests the
+// nodes (or primitives) of BOTH rays before it tests either, so that one ray's LDS round trip hides
+// behind the other's arithmetic.  12 waves x 2 rays are 24 dependent chains per CU where 16 waves
+// x 1 ray are 16, with ONE copy of the scene in LDS (24 waves of one ray each would need two blocks
+// per CU and two copies, which do not fit).  Per ray the operations are exactly those of mode 7.
+// (The slot-exchange experiment of round 2 - modes 8-10 then, profiles/r02/experiments.txt H and J -
+// was a measured negative and is gone from the source.)
 template <int STATS, int REFILL, int MODE>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RTGPU_WAVES_PER_EU, RTGPU_WAVES_PER_EU)))
+__global__ __launch_bounds__(MODE == 8 ? kBlock2 : kBlock)
+__attribute__((amdgpu_waves_per_eu(MODE == 8 ? kBlock2 * RTGPU_BLOCKS_PER_CU / 256 : RTGPU_WAVES_PER_EU,
+                                   MODE == 8 ? kBlock2 * RTGPU_BLOCKS_PER_CU / 256 : RTGPU_WAVES_PER_EU)))
 void trace_kernel(const KParams P) {
-  constexpr bool LDS_ONLY = MODE == 1 || MODE == 2 || MODE == 4 || (MODE >= 6 && MODE <= 9), SMALL = MODE == 2 || MODE == 7 || MODE == 8,
-                 TINY = MODE == 7 || MODE == 8, DUAL = MODE >= 8, PACKED = MODE == 3 || MODE == 4,
-                 WIDE = MODE == 5 || MODE == 6 || MODE >= 9, HYBRID = MODE == 5 || MODE == 10;
+  constexpr bool LDS_ONLY = MODE == 1 || MODE == 2 || MODE == 4 || MODE == 6 || MODE == 7 || MODE == 8, SMALL = MODE == 2 || MODE == 7 || MODE == 8,
+                 TINY = MODE == 7 || MODE == 8, PACKED = MODE == 3 || MODE == 4,
+                 WIDE = MODE == 5 || MODE == 6, HYBRID = MODE == 5;
+  constexpr int R = MODE == 8 ? 2 : 1;                  // rays a lane traverses in lock step
+  constexpr int BLOCK = MODE == 8 ? kBlock2 : kBlock;   // threads per block
+  constexpr int STRIDE = BLOCK * R;                     // words between consecutive entries of one stack
 #ifdef RTGPU_NO_HIT_NORMAL  // experiments: shading fetches the triangle again
   constexpr bool KEEP_N = false;
 #else
@@ -426,7 +431,7 @@ void trace_kernel(const KParams P) {
 #define RTGPU_TINY_TRIS 1
 #endif
   constexpr int TRIS = TINY ? RTGPU_TINY_TRIS : SMALL ? 1 : kTriStep;  // triangles per leaf step (two in the LDS mode measured C2 1.4 % slower)
-  // LDS: [traversal stacks: stack_lds x kBlock u32][node cache: 4 planes x n_cached float4]
+  // LDS: [traversal stacks: stack_lds x R x BLOCK u32][node cache: 4 planes x n_cached float4]
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   uint32_t *const lds_stack = smem;
   // explicit LDS address space: otherwise hipcc folds the "cached or not" choice
@@ -434,68 +439,84 @@ void trace_kernel(const KParams P) {
   // LDS reads go through the texture addresser like global ones
   typedef float f4 __attribute__((ext_vector_type(4)));
   typedef __attribute__((address_space(3))) f4 lds_f4;
-  lds_f4 *const node_cache = (lds_f4 *)(smem + P.stack_lds * kBlock);
+  lds_f4 *const node_cache = (lds_f4 *)(smem + P.stack_lds * STRIDE);
   const unsigned tid = threadIdx.x;
   const unsigned lane = lane_id();
 
-  const V3 cam_o = ld3(P.cam_origin), cam_ll = ld3(P.cam_ll), cam_hor = ld3(P.cam_hor),
-           cam_ver = ld3(P.cam_ver);
-  const uint32_t ts = 1u << P.ts_log2;
-  const uint32_t blocks_per_row_log2 = P.ts_log2 - 3u;  // 8x8 pixel blocks per tile row
+  // The kernel is at the scalar-register limit (106), and what does not fit is spilled to lanes of a vector register:
+  // a v_readlane (+ its wait states) wherever such a value is used - 48 of them in the loop of the scene-in-LDS kernel,
+  // and the time follows their number (11 more cost C2 2.4 %).  So the parameters that only the COLD sections read -
+  // camera, sky, frame and tile geometry, output pointers - are not kept in registers across the loop: those sections
+  // read them from the kernel-argument segment where they use them (s_load through the scalar cache).  The empty asm
+  // keeps the compiler from hoisting the loads back out of the loop.
+  typedef const __attribute__((address_space(4))) KParams *KArgs;
+  auto kargs = [&]() __attribute__((always_inline)) {
+    KArgs k = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(k));
+    return k;
+  };
+  // The kernels of the scenes in LDS need fewer scalar registers (no scene pointers in the loop) and run their cold
+  // sections more often per unit of time: camera and sky stay in registers there (74 + 18 scalar registers, no spill).
+  constexpr bool HOIST_CAM = SMALL;
+  const V3 cam_o_h = ld3(P.cam_origin), cam_ll_h = ld3(P.cam_ll), cam_hor_h = ld3(P.cam_hor), cam_ver_h = ld3(P.cam_ver);
+  const V3 sky_b_h = ld3(P.sky_bottom), sky_t_h = ld3(P.sky_top);
 
-  // lane state
-  bool done = false, alive = false, have_pixel = false, pixel_valid = false;
-  uint32_t px = 0, py = 0, out_index = 0, sample = 0, sample_end = 0, chunk = 0, bounce = 0,
-           first_id = RTGPU_NO_HIT;
-  V3 sum = mk(0.f, 0.f, 0.f), thr = mk(1.f, 1.f, 1.f), ro = mk(0.f, 0.f, 0.f), rd = mk(0.f, 0.f, 1.f);
-  Rng rng = {0u};
-  V3 new_dir = mk(0.f, 0.f, 1.f);  // unnormalised direction of the segment about to start
+  // state of one ray of the lane: the work item it belongs to, its path, and its traversal
+  // (which survives an early exit from the traversal loop)
+  typedef Stack<LDS_ONLY, STRIDE> StackT;
+  struct Ray {
+    bool done, alive, have_pixel, pixel_valid;
+    uint32_t px, py, out_index, sample, sample_end, chunk, bounce, first_id;
+    V3 sum, thr, ro, rd;
+    Rng rng;
+    V3 new_dir;  // unnormalised direction of the segment about to start
+    f2 inv_xy, inv_zx, inv_yz, noi_xy, noi_zx, noi_yz;
+    float tbest;
+    uint32_t cur;
+    // closest hit so far: the leaf cursor at the time of the hit (type bit + slot of the
+    // primitive in its leaf-ordered array), kDone = none
+    uint32_t hit_ref;
+    // material index of the closest TRIANGLE hit so far, taken from the record the test has in
+    // registers: shading then fetches the material together with the triangle instead of after it
+    uint32_t hit_mat;
+    // trees in memory (not MODE 2, 7, 8): the closest triangle's e1 x e2 and id are kept too, so that shading does not
+    // fetch the record again (a dependent round trip through the vector memory pipeline per shading pass)
+    V3 hit_n;
+    uint32_t hit_prim;
+    StackT stk;
+  };
+  // (named objects, not an array: the compiler splits them into registers before it looks at any loop)
+  Ray ray0, ray1;  // ray1: R == 2 only
+  auto init_ray = [&](Ray &S, int r) __attribute__((always_inline)) {
+    S.done = S.alive = S.have_pixel = S.pixel_valid = false;
+    S.px = S.py = S.out_index = S.sample = S.sample_end = S.chunk = S.bounce = 0u;
+    S.first_id = RTGPU_NO_HIT;
+    S.sum = mk(0.f, 0.f, 0.f); S.thr = mk(1.f, 1.f, 1.f); S.ro = mk(0.f, 0.f, 0.f); S.rd = mk(0.f, 0.f, 1.f);
+    S.rng.s = 0u;
+    S.new_dir = mk(0.f, 0.f, 1.f);
+    S.inv_xy = mk2(1.f, 1.f); S.inv_zx = S.inv_xy; S.inv_yz = S.inv_xy;
+    S.noi_xy = mk2(0.f, 0.f); S.noi_zx = S.noi_xy; S.noi_yz = S.noi_xy;
+    S.tbest = kTMax;
+    S.cur = kDone; S.hit_ref = kDone; S.hit_mat = 0u;
+    S.hit_n = mk(0.f, 0.f, 1.f); S.hit_prim = 0u;
+    S.stk.lds = lds_stack + r * BLOCK + tid;
+    S.stk.base_at = (typename StackT::lds_u32 *)(lds_stack + r * BLOCK + tid);
+    S.stk.top_at = S.stk.base_at;
+    S.stk.ovf_stride = gridDim.x * BLOCK;
+    S.stk.ovf = P.ovf_stack + (size_t)blockIdx.x * BLOCK + tid;
+    S.stk.sp = 1;
+    S.stk.lds_entries = (int)P.stack_lds;
+    lds_stack[r * BLOCK + tid] = kDone;  // sentinel under every stack (never overwritten)
+  };
+  init_ray(ray0, 0);
+  init_ray(ray1, R - 1);  // (R == 1: the same words again; ray1 is then never used)
   unsigned long long n_paths = 0, n_rays = 0, n_nodes = 0, n_tris = 0, n_sphs = 0, n_scat = 0;
   unsigned long long w_outer = 0, w_shade = 0, l_shade = 0, w_gen = 0, w_node = 0, w_sph = 0, w_tri = 0,
                      w_trav = 0, l_trav = 0, l_node = 0, l_cached = 0, w_slow = 0, t_node = 0, t_leaf = 0;
-  // traversal state (survives an early exit from the traversal loop)
-  V3 inv = mk(1.f, 1.f, 1.f), noi = mk(0.f, 0.f, 0.f);
-  f2 inv_xy = mk2(1.f, 1.f), inv_zx = inv_xy, inv_yz = inv_xy, noi_xy = mk2(0.f, 0.f), noi_zx = noi_xy, noi_yz = noi_xy;
-  float tbest = kTMax;
-  uint32_t cur = kDone;
-  // closest hit so far: the leaf cursor at the time of the hit (type bit + slot of the
-  // primitive in its leaf-ordered array), kDone = none
-  uint32_t hit_ref = kDone;
-  // material index of the closest TRIANGLE hit so far, taken from the record the test has in
-  // registers: shading then fetches the material together with the triangle instead of after it
-  uint32_t hit_mat = 0u;
-  // trees in memory (not MODE 2, 7, 8): the closest triangle's e1 x e2 and id are kept too, so that shading does not
-  // fetch the record again (a dependent round trip through the vector memory pipeline per shading pass)
-  V3 hit_n = mk(0.f, 0.f, 1.f);
-  uint32_t hit_prim = 0u;
   unsigned pool_next = 0, pool_end = 0;  // wave-local slice of the work queue (wave-uniform)
   // wave-uniform description of the group the pool was drawn from (see (2))
   uint32_t g_px = 0, g_py = 0, g_out = 0, g_row = 0, g_chunk = 0, g_sample = 0, g_sample_end = 0;
   bool queue_dry = false;                // wave-uniform: the global head has passed n_items
-  Stack<LDS_ONLY> stk;
-  stk.lds = lds_stack + tid;
-  stk.base_at = (typename Stack<LDS_ONLY>::lds_u32 *)(lds_stack + tid);
-  stk.top_at = stk.base_at;
-  stk.ovf_stride = gridDim.x * kBlock;
-  stk.ovf = P.ovf_stack + (size_t)blockIdx.x * kBlock + tid;
-  stk.sp = 1;
-  stk.lds_entries = (int)P.stack_lds;
-  lds_stack[tid] = kDone;  // sentinel under every lane's stack (never overwritten)
-  // MODE 8 (experiment, RTGPU_DUAL=1): every lane owns TWO work items.  Slot P is the one in the registers above;
-  // slot Q keeps its path state in the registers below and its ray (origin | tbest, direction | hit) in a 32-byte
-  // LDS record.  A lane whose traversal ends while its other slot holds a ray ready to go exchanges the two in the
-  // middle of a traversal round (swap_slots) instead of idling to the round's end; the results wait in the record
-  // for the next shading pass.  Only one of the two rays is ever in mid-traversal (the lane has one stack).
-  bool q_alive = false, q_done = false, q_have_pixel = false, q_pixel_valid = false;
-  uint32_t q_px = 0, q_py = 0, q_out_index = 0, q_sample = 0, q_sample_end = 0, q_chunk = 0, q_bounce = 0,
-           q_first_id = RTGPU_NO_HIT;
-  V3 q_sum = mk(0.f, 0.f, 0.f), q_thr = mk(1.f, 1.f, 1.f);
-  Rng q_rng = {0u};
-  uint32_t qcur = kDone, q_hit_mat = 0u, q_hit_prim = 0u;
-  int q_sp = 1;
-  V3 q_hit_n = mk(0.f, 0.f, 1.f);
-  typename Stack<LDS_ONLY>::lds_u32 *q_top = stk.base_at;
-  unsigned long long w_swap = 0, l_swap = 0;
   // LDS copy of the n_cached nodes nearest the root (the builder numbers them
   // breadth-first), as four planes [16-byte quarter][node]: lanes of a wave read
   // quarter j of DIFFERENT nodes, and in this layout consecutive nodes sit in
@@ -504,7 +525,7 @@ void trace_kernel(const KParams P) {
   const uint32_t n_cached = (SMALL || HYBRID) ? P.n_cached : 0u;
   constexpr uint32_t plane = (uint32_t)(TINY ? kTinyNodes : kSmallNodes);  // nodes per plane
   if (SMALL)
-    for (uint32_t i = tid; i < n_cached * 4u; i += kBlock) {
+    for (uint32_t i = tid; i < n_cached * 4u; i += BLOCK) {
       float4 v = P.nodes[i];
       f4 w = {v.x, v.y, v.z, v.w};
       node_cache[(i & 3u) * plane + (i >> 2)] = w;
@@ -514,7 +535,7 @@ void trace_kernel(const KParams P) {
   lds_f4 *const sph_cache = node_cache + 4 * plane;
   const bool sph_in_lds = TINY || (SMALL && P.sph_cached != 0u);
   if (sph_in_lds)
-    for (uint32_t i = tid; i < P.sph_cached; i += kBlock) {
+    for (uint32_t i = tid; i < P.sph_cached; i += BLOCK) {
       float4 v = P.sphs[i];
       f4 w = {v.x, v.y, v.z, TINY ? v.w * v.w : v.w};  // MODE 7: centre | r^2 (shading has 1/r in its own record)
       sph_cache[i] = w;
@@ -527,12 +548,12 @@ void trace_kernel(const KParams P) {
          *const sphmat_cache = node_cache + kTinySphMatAt, *const trimat_cache = node_cache + kTinyTriMatAt;
   lds_u2 *const meta_cache = (lds_u2 *)(node_cache + kTinyMetaAt);
   if (TINY) {
-    for (uint32_t i = tid; i < P.tiny_tris * 3u; i += kBlock) {
+    for (uint32_t i = tid; i < P.tiny_tris * 3u; i += BLOCK) {
       float4 v = P.tris[i];
       f4 w = {v.x, v.y, v.z, v.w};
       tri_cache[i] = w;
     }
-    for (uint32_t i = tid; i < P.tiny_tris; i += kBlock) {
+    for (uint32_t i = tid; i < P.tiny_tris; i += BLOCK) {
       const float4 t0 = P.tris[3u * i], t1 = P.tris[3u * i + 1u], t2 = P.tris[3u * i + 2u];
       const V3 n = normalize(cross(mk(t1.x, t1.y, t1.z), mk(t2.x, t2.y, t2.z)));
       const f4 w = {n.x, n.y, n.z, t0.w};  // unit normal | id
@@ -543,7 +564,7 @@ void trace_kernel(const KParams P) {
       trimat_cache[2u * i] = wa;
       trimat_cache[2u * i + 1u] = wb;
     }
-    for (uint32_t i = tid; i < P.sph_cached; i += kBlock) {
+    for (uint32_t i = tid; i < P.sph_cached; i += BLOCK) {
       const uint2 v = P.sph_meta[i];
       const u2 w = {v.x, __float_as_uint(rcp_exact(P.sphs[i].w))};  // id | 1/r
       meta_cache[i] = w;
@@ -556,9 +577,9 @@ void trace_kernel(const KParams P) {
   // Trees in memory: a small material table (<= kLdsMats entries) behind the stacks, so that the shading pass waits
   // for no vector load at all (the triangle's normal and id are in registers, KEEP_N)
   lds_f4 *const mats_lds = node_cache + ((HYBRID && n_cached) ? 6 * kWideCached : 0);
-  const bool mats_in_lds = !SMALL && !DUAL && P.mats_cached != 0u;
+  const bool mats_in_lds = !SMALL && P.mats_cached != 0u;
   if (mats_in_lds)
-    for (uint32_t i = tid; i < P.mats_cached * 2u; i += kBlock) {
+    for (uint32_t i = tid; i < P.mats_cached * 2u; i += BLOCK) {
       float4 v = P.mats[i];
       f4 w = {v.x, v.y, v.z, v.w};
       mats_lds[i] = w;
@@ -572,44 +593,12 @@ void trace_kernel(const KParams P) {
     }
   };
   if (HYBRID)  // quarter j of four-wide node k -> plane j, slot k
-    for (uint32_t i = tid; i < n_cached * 6u; i += kBlock) {
+    for (uint32_t i = tid; i < n_cached * 6u; i += BLOCK) {
       float4 v = P.nodes[i];
       f4 w = {v.x, v.y, v.z, v.w};
       const uint32_t k = i / 6u;
       node_cache[(i - k * 6u) * (uint32_t)kWideCached + k] = w;
     }
-  lds_f4 *const rec = node_cache + (TINY ? kTinyEnd : 0) + tid;  // MODE 8, 9: [2][kBlock] records behind the scene / the stacks
-  if (DUAL) {
-    const f4 z = {0.f, 0.f, 0.f, 0.f};
-    rec[0] = z;
-    rec[kBlock] = z;
-  }
-  auto swap_slots = [&](bool doit) __attribute__((always_inline)) {
-    if (STATS == 2) { wave_tick(lane, w_swap); if (doit) l_swap++; }
-    if (doit) {
-      const f4 a = rec[0], b = rec[kBlock];
-      const f4 na = {ro.x, ro.y, ro.z, tbest}, nb = {rd.x, rd.y, rd.z, __uint_as_float(hit_ref)};
-      rec[0] = na;
-      rec[kBlock] = nb;
-      ro = mk(a.x, a.y, a.z); tbest = a.w;
-      rd = mk(b.x, b.y, b.z); hit_ref = __float_as_uint(b.w);
-#define RTGPU_SW(x, y) do { auto t_ = x; x = y; y = t_; } while (0)
-      RTGPU_SW(hit_mat, q_hit_mat); RTGPU_SW(cur, qcur); RTGPU_SW(stk.top_at, q_top); RTGPU_SW(stk.sp, q_sp);
-      if (KEEP_N) { RTGPU_SW(hit_n.x, q_hit_n.x); RTGPU_SW(hit_n.y, q_hit_n.y); RTGPU_SW(hit_n.z, q_hit_n.z); RTGPU_SW(hit_prim, q_hit_prim); }
-      RTGPU_SW(px, q_px); RTGPU_SW(py, q_py); RTGPU_SW(out_index, q_out_index); RTGPU_SW(sample, q_sample);
-      RTGPU_SW(sample_end, q_sample_end); RTGPU_SW(chunk, q_chunk); RTGPU_SW(bounce, q_bounce);
-      RTGPU_SW(first_id, q_first_id); RTGPU_SW(sum.x, q_sum.x); RTGPU_SW(sum.y, q_sum.y); RTGPU_SW(sum.z, q_sum.z);
-      RTGPU_SW(thr.x, q_thr.x); RTGPU_SW(thr.y, q_thr.y); RTGPU_SW(thr.z, q_thr.z); RTGPU_SW(rng.s, q_rng.s);
-      RTGPU_SW(alive, q_alive); RTGPU_SW(done, q_done); RTGPU_SW(have_pixel, q_have_pixel);
-      RTGPU_SW(pixel_valid, q_pixel_valid);
-#undef RTGPU_SW
-      // what (3) derived from the ray: the same operations on the same values
-      inv = mk(rcp_fast(clamp_dir(rd.x)), rcp_fast(clamp_dir(rd.y)), rcp_fast(clamp_dir(rd.z)));
-      noi = mk(-(ro.x * inv.x), -(ro.y * inv.y), -(ro.z * inv.z));
-      inv_xy = mk2(inv.x, inv.y); inv_zx = mk2(inv.z, inv.x); inv_yz = mk2(inv.y, inv.z);
-      noi_xy = mk2(noi.x, noi.y); noi_zx = mk2(noi.z, noi.x); noi_yz = mk2(noi.y, noi.z);
-    }
-  };
   __syncthreads();
   const float tmin = P.tmin;
   const uint32_t seed_hash = pcg(P.seed);
@@ -626,35 +615,33 @@ void trace_kernel(const KParams P) {
 
   unsigned long long n_after_dry = 0;
   for (;;) {
-    // MODE 8: shading passes while enough lanes hold a result in their other slot; a lane whose slot P needs
-    // nothing brings slot Q in first (parking a ray in mid-traversal in the record if it has to)
-    bool again = false;  // wave-uniform
-    do {
-    if (DUAL) {
-      const bool need_p = alive ? cur == kDone : !done;
-      const bool need_q = q_alive ? qcur == kDone : !q_done;
-      swap_slots(need_q && !need_p);
-    }
-    // ---- (1) shade the rays whose traversal has finished (rows a6, a8) ----------
     if (STATS == 2) { wave_tick(lane, w_outer); if (queue_dry) n_after_dry++; }
-    if (alive && cur == kDone) {
+    // sections (1)-(3) for one ray of the lane; true if the ray is in flight afterwards
+    auto outer_sections = [&](Ray &S) __attribute__((always_inline)) {
+    // ---- (1) shade the rays whose traversal has finished (rows a6, a8) ----------
+    if (S.alive && S.cur == kDone) {
       if (STATS == 2) { wave_tick(lane, w_shade); l_shade++; }
       V3 L = mk(0.f, 0.f, 0.f);
       bool path_end = false;
-      const uint32_t hit_slot = RTGPU_REF_FIRST(hit_ref);
-      if (hit_ref == kDone) {
-        float t = 0.5f * (rd.y + 1.0f);
+      const uint32_t hit_slot = RTGPU_REF_FIRST(S.hit_ref);
+      if (S.hit_ref == kDone) {
+        float t = 0.5f * (S.rd.y + 1.0f);
         float a = 1.0f - t;
-        V3 sky = mk(P.sky_bottom[0] * a + P.sky_top[0] * t, P.sky_bottom[1] * a + P.sky_top[1] * t,
-                    P.sky_bottom[2] * a + P.sky_top[2] * t);
-        L = thr * sky;
+        V3 sb = sky_b_h, stp = sky_t_h;
+        if (!HOIST_CAM) {
+          KArgs K = kargs();
+          sb = mk(K->sky_bottom[0], K->sky_bottom[1], K->sky_bottom[2]);
+          stp = mk(K->sky_top[0], K->sky_top[1], K->sky_top[2]);
+        }
+        V3 sky = mk(sb.x * a + stp.x * t, sb.y * a + stp.y * t, sb.z * a + stp.z * t);
+        L = S.thr * sky;
         path_end = true;
       } else {
-        V3 p = ro + rd * tbest;
+        V3 p = S.ro + S.rd * S.tbest;
         V3 n;
         uint32_t prim;
         float4 m0, m1;
-        if (hit_ref & RTGPU_REF_SPHERE) {
+        if (S.hit_ref & RTGPU_REF_SPHERE) {
           float4 s;
           if (sph_in_lds) { const f4 w = sph_cache[hit_slot]; s = make_float4(w.x, w.y, w.z, w.w); }
           else s = P.sphs[hit_slot];
@@ -682,17 +669,17 @@ void trace_kernel(const KParams P) {
           } else if (!KEEP_N) {
             const float4 *tp = P.tris + (size_t)hit_slot * (sizeof(rtgpu_tri) / 16);
             const float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
-            load_mat(hit_mat, m0, m1);
+            load_mat(S.hit_mat, m0, m1);
             n = normalize(cross(mk(t1.x, t1.y, t1.z), mk(t2.x, t2.y, t2.z)));
             prim = __float_as_uint(t0.w);
           } else {
-            load_mat(hit_mat, m0, m1);
-            n = normalize(hit_n);
-            prim = hit_prim;
+            load_mat(S.hit_mat, m0, m1);
+            n = normalize(S.hit_n);
+            prim = S.hit_prim;
           }
         }
-        if (bounce == 0 && sample == 0) first_id = prim;
-        float dn = dot(rd, n);
+        if (S.bounce == 0 && S.sample == 0) S.first_id = prim;
+        float dn = dot(S.rd, n);
         bool front = dn < 0.0f;
         if (!front) n = neg(n);
 
@@ -706,7 +693,7 @@ void trace_kernel(const KParams P) {
         // operations and the RNG draws are exactly the oracle's.
         const bool is_lamb = mtype == RTGPU_MAT_LAMBERTIAN, is_metal = mtype == RTGPU_MAT_METAL;
         V3 ruv = mk(0.f, 0.f, 0.f);
-        if (is_lamb || (is_metal && param > 0.0f)) ruv = random_unit_vector(rng);
+        if (is_lamb || (is_metal && param > 0.0f)) ruv = random_unit_vector(S.rng);
         V3 sd;
         bool absorbed = false;
         if (is_lamb) {
@@ -714,18 +701,18 @@ void trace_kernel(const KParams P) {
           if (__builtin_fabsf(sd.x) < 1e-8f && __builtin_fabsf(sd.y) < 1e-8f && __builtin_fabsf(sd.z) < 1e-8f)
             sd = n;
         } else if (is_metal) {
-          sd = reflect(rd, n);  // unit to rounding: rd and n are
+          sd = reflect(S.rd, n);  // unit to rounding: rd and n are
           if (param > 0.0f) sd = sd + ruv * param;
           absorbed = !(dot(sd, n) > 0.0f);
         } else if (mtype == RTGPU_MAT_EMISSIVE) {
-          L = thr * (albedo * param);  // a light ends the path with its radiance, from either face
+          L = S.thr * (albedo * param);  // a light ends the path with its radiance, from either face
           sd = n;
           absorbed = true;
         } else {
           // 1/ior and Schlick's r0 per face come precomputed with the flattened
           // material (bvh_build.cpp): the same f32 operations, done once on the host
           float ri = front ? m1.y : param;
-          float cos_t = fmin_(-dot(rd, n), 1.0f);
+          float cos_t = fmin_(-dot(S.rd, n), 1.0f);
           float sin_t = sqrt_exact(1.0f - cos_t * cos_t);
           bool cannot = ri * sin_t > 1.0f;
           float r0 = front ? m1.z : m1.w;
@@ -733,11 +720,11 @@ void trace_kernel(const KParams P) {
           float x2 = xx * xx;
           float x5 = x2 * x2 * xx;
           float refl = r0 + (1.0f - r0) * x5;
-          float u = rng.u01();
+          float u = S.rng.u01();
           if (cannot || refl > u) {
-            sd = reflect(rd, n);
+            sd = reflect(S.rd, n);
           } else {
-            V3 perp = (rd + n * cos_t) * ri;
+            V3 perp = (S.rd + n * cos_t) * ri;
             float par = -sqrt_exact(__builtin_fabsf(1.0f - dot(perp, perp)));
             sd = perp + n * par;
           }
@@ -745,38 +732,39 @@ void trace_kernel(const KParams P) {
         if (absorbed) {
           path_end = true;
         } else {
-          thr = thr * albedo;
-          ro = p;
-          new_dir = sd;  // normalised in (3), together with fresh camera rays
-          bounce++;
-          if (bounce >= P.max_depth) path_end = true;  // depth exhausted: L stays 0
+          S.thr = S.thr * albedo;
+          S.ro = p;
+          S.new_dir = sd;  // normalised in (3), together with fresh camera rays
+          S.bounce++;
+          if (S.bounce >= P.max_depth) path_end = true;  // depth exhausted: L stays 0
         }
       }
       if (path_end) {
-        sum = sum + L;
-        sample++;
-        alive = false;
+        S.sum = S.sum + L;
+        S.sample++;
+        S.alive = false;
       }
     }
 
     SECTION_END(c_shade);
     // ---- (2) lanes without a path in flight: next sample, or next pixel ---------
-    bool need_pixel = !alive && !done && (!have_pixel || sample >= sample_end);
-    if (need_pixel && have_pixel) {
-      if (pixel_valid) {
-        if (P.n_chunks > 1u) {
-          P.planes[(size_t)chunk * P.plane_stride + out_index] = make_float4(sum.x, sum.y, sum.z, 0.0f);
+    bool need_pixel = !S.alive && !S.done && (!S.have_pixel || S.sample >= S.sample_end);
+    if (need_pixel && S.have_pixel) {
+      if (S.pixel_valid) {
+        KArgs K = kargs();
+        if (K->n_chunks > 1u) {
+          K->planes[(size_t)S.chunk * K->plane_stride + S.out_index] = make_float4(S.sum.x, S.sum.y, S.sum.z, 0.0f);
         } else {
-          float4 o = make_float4(sum.x, sum.y, sum.z, (float)P.spp);
-          if (P.flags & RTGPU_FLAG_ACCUMULATE) {
-            float4 in = P.accum[out_index];
+          float4 o = make_float4(S.sum.x, S.sum.y, S.sum.z, (float)K->spp);
+          if (K->flags & RTGPU_FLAG_ACCUMULATE) {
+            float4 in = K->accum[S.out_index];
             o.x = in.x + o.x; o.y = in.y + o.y; o.z = in.z + o.z; o.w = in.w + o.w;
           }
-          P.accum[out_index] = o;
+          K->accum[S.out_index] = o;
         }
-        if (P.prim_id && chunk == 0u) P.prim_id[out_index] = first_id;
+        if (K->prim_id && S.chunk == 0u) K->prim_id[S.out_index] = S.first_id;
       }
-      have_pixel = false;
+      S.have_pixel = false;
     }
     // Work queue: the global head is one word, and a returning atomic on one word
     // saturates near 88 per microsecond chip-wide (MI355X_MICROARCH.md, row
@@ -792,69 +780,72 @@ void trace_kernel(const KParams P) {
     unsigned long long need_mask = __ballot(need_pixel);
     while (need_mask != 0ull) {  // wave-uniform, at most two rounds
       if (pool_next == pool_end) {  // wave-uniform: draw the next group
+        KArgs K = kargs();
+        const uint32_t ts = 1u << K->ts_log2;
+        const uint32_t blocks_per_row_log2 = K->ts_log2 - 3u;  // 8x8 pixel blocks per tile row
         // once a wave has seen the queue dry it never asks again: thousands of
         // waves polling a dry head with one atomic per iteration saturate the
         // atomic unit and stretch the tail of the launch
-        unsigned nb = P.n_items;
+        unsigned nb = K->n_items;
         if (!queue_dry) {
           const unsigned leader = (unsigned)__ffsll((long long)need_mask) - 1u;
           unsigned long long fetched = 0ull;
-          if (lane == leader) fetched = atomicAdd(&P.counters[0], (unsigned long long)kChunk);
+          if (lane == leader) fetched = atomicAdd(&K->counters[0], (unsigned long long)kChunk);
           fetched = __shfl(fetched, (int)leader, 64);
           // a head beyond n_items means the queue is dry; clamp so u32 math cannot wrap
-          nb = fetched >= (unsigned long long)P.n_items ? P.n_items : (unsigned)fetched;
+          nb = fetched >= (unsigned long long)K->n_items ? K->n_items : (unsigned)fetched;
           nb = (unsigned)__builtin_amdgcn_readfirstlane((int)nb);
         }
-        if (nb >= P.n_items) {
+        if (nb >= K->n_items) {
           queue_dry = true;
           if (STATS == 2 && t_dry == 0) t_dry = __builtin_amdgcn_s_memrealtime();
-          if (need_pixel) done = true;
+          if (need_pixel) S.done = true;
           break;
         }
         pool_next = nb;
         pool_end = nb + kChunk;  // n_items is a multiple of kChunk
         // group -> (64-pixel group, chunk of samples): groups x chunks, pixel-group-major
         uint32_t grp = nb >> 6, pix_grp = grp, chunk_u = 0u;
-        if (P.n_chunks > 1u) {
-          if (P.groups_small) {  // float estimate, exact below 2^22, corrected by at most one
-            pix_grp = (uint32_t)((float)grp * P.inv_n_chunks);
-            int rem = (int)(grp - pix_grp * P.n_chunks);
-            pix_grp += (rem >= (int)P.n_chunks) ? 1u : 0u;
+        if (K->n_chunks > 1u) {
+          if (K->groups_small) {  // float estimate, exact below 2^22, corrected by at most one
+            pix_grp = (uint32_t)((float)grp * K->inv_n_chunks);
+            int rem = (int)(grp - pix_grp * K->n_chunks);
+            pix_grp += (rem >= (int)K->n_chunks) ? 1u : 0u;
             pix_grp -= (rem < 0) ? 1u : 0u;
           } else {
-            pix_grp = grp / P.n_chunks;
+            pix_grp = grp / K->n_chunks;
           }
           pix_grp = (uint32_t)__builtin_amdgcn_readfirstlane((int)pix_grp);
-          chunk_u = grp - pix_grp * P.n_chunks;
+          chunk_u = grp - pix_grp * K->n_chunks;
         }
         // pixel group -> (local tile j, 8x8 block in the tile)
         const uint32_t it = pix_grp << 6;
-        const uint32_t k = it & (ts * ts - 1u), j = it >> (2u * P.ts_log2);
+        const uint32_t k = it & (ts * ts - 1u), j = it >> (2u * K->ts_log2);
         const uint32_t blk = k >> 6;
         const uint32_t tx = (blk & ((1u << blocks_per_row_log2) - 1u)) << 3;
         const uint32_t ty = (blk >> blocks_per_row_log2) << 3;
-        const uint32_t tile = P.rank + j * P.world;
+        const uint32_t tile = K->rank + j * K->world;
         // tile / tiles_x without the integer division: a float estimate (exact
         // operands below 2^22) corrected by at most one
         uint32_t tile_y;
-        if (P.tiles_small) {
-          tile_y = (uint32_t)((float)tile * P.inv_tiles_x);
-          int rem = (int)(tile - tile_y * P.tiles_x);
-          tile_y += (rem >= (int)P.tiles_x) ? 1u : 0u;
+        if (K->tiles_small) {
+          tile_y = (uint32_t)((float)tile * K->inv_tiles_x);
+          int rem = (int)(tile - tile_y * K->tiles_x);
+          tile_y += (rem >= (int)K->tiles_x) ? 1u : 0u;
           tile_y -= (rem < 0) ? 1u : 0u;
         } else {
-          tile_y = tile / P.tiles_x;
+          tile_y = tile / K->tiles_x;
         }
         tile_y = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile_y);
-        const uint32_t tile_x = tile - tile_y * P.tiles_x;
-        g_px = (tile_x << P.ts_log2) + tx;
-        g_py = (tile_y << P.ts_log2) + ty;
-        g_row = (P.flags & RTGPU_FLAG_COMPACT) ? ts : P.width;  // output slots per image row
-        g_out = (P.flags & RTGPU_FLAG_COMPACT) ? (j << (2u * P.ts_log2)) + (ty << P.ts_log2) + tx
-                                                : g_py * P.width + g_px;
+        const uint32_t tile_x = tile - tile_y * K->tiles_x;
+        g_px = (tile_x << K->ts_log2) + tx;
+        g_py = (tile_y << K->ts_log2) + ty;
+        g_row = (K->flags & RTGPU_FLAG_COMPACT) ? ts : K->width;  // output slots per image row
+        g_out = (K->flags & RTGPU_FLAG_COMPACT) ? (j << (2u * K->ts_log2)) + (ty << K->ts_log2) + tx
+                                                : g_py * K->width + g_px;
         g_chunk = chunk_u;
-        g_sample = chunk_u * P.chunk_samples;
-        g_sample_end = g_sample + P.chunk_samples < P.spp ? g_sample + P.chunk_samples : P.spp;
+        g_sample = chunk_u * K->chunk_samples;
+        g_sample_end = g_sample + K->chunk_samples < K->spp ? g_sample + K->chunk_samples : K->spp;
       }
       const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(need_mask >> 32),
                                                       __builtin_amdgcn_mbcnt_lo((unsigned)need_mask, 0u));
@@ -862,107 +853,113 @@ void trace_kernel(const KParams P) {
       const unsigned avail = pool_end - pool_next;  // wave-uniform, >= 1
       if (need_pixel && rank < avail) {
         const uint32_t within = (pool_next + rank) & 63u, wx = within & 7u, wy = within >> 3;
-        px = g_px + wx;
-        py = g_py + wy;
-        pixel_valid = px < P.width && py < P.height;
-        out_index = g_out + __umul24(wy, g_row) + wx;  // both below 2^24 (width <= 65536): v_mad_u32_u24 is full rate
-        chunk = g_chunk;
-        have_pixel = true;
-        sample = pixel_valid ? g_sample : g_sample_end;  // out-of-image pixel: nothing to trace
-        sample_end = g_sample_end;
-        sum = mk(0.f, 0.f, 0.f);
-        first_id = RTGPU_NO_HIT;
+        S.px = g_px + wx;
+        S.py = g_py + wy;
+        S.pixel_valid = S.px < P.width && S.py < P.height;
+        S.out_index = g_out + __umul24(wy, g_row) + wx;  // both below 2^24 (width <= 65536): v_mad_u32_u24 is full rate
+        S.chunk = g_chunk;
+        S.have_pixel = true;
+        S.sample = S.pixel_valid ? g_sample : g_sample_end;  // out-of-image pixel: nothing to trace
+        S.sample_end = g_sample_end;
+        S.sum = mk(0.f, 0.f, 0.f);
+        S.first_id = RTGPU_NO_HIT;
         need_pixel = false;
       }
       pool_next += cnt < avail ? cnt : avail;
       need_mask = __ballot(need_pixel);
     }
     SECTION_END(c_item);
-    if (!alive && !done && have_pixel && sample < sample_end) {
+    if (!S.alive && !S.done && S.have_pixel && S.sample < S.sample_end) {
       // ---- camera ray (row a1) ----
       if (STATS == 2) wave_tick(lane, w_gen);
-      rng.start(pcg((P.sample_offset + sample) ^ pcg((__umul24(py, P.width) + px) ^ seed_hash)));
-      float jx = rng.u01(), jy = rng.u01();
-      float sx = ((float)px + jx) * P.inv_w;
-      float sy = ((float)py + jy) * P.inv_h;
+      KArgs K = kargs();
+      V3 cam_o = cam_o_h, cam_ll = cam_ll_h, cam_hor = cam_hor_h, cam_ver = cam_ver_h;
+      float inv_w = P.inv_w, inv_h = P.inv_h, lens_radius = P.lens_radius;
+      uint32_t sample_offset = P.sample_offset, width = P.width;
+      if (!HOIST_CAM) {
+        cam_o = mk(K->cam_origin[0], K->cam_origin[1], K->cam_origin[2]); cam_ll = mk(K->cam_ll[0], K->cam_ll[1], K->cam_ll[2]);
+        cam_hor = mk(K->cam_hor[0], K->cam_hor[1], K->cam_hor[2]); cam_ver = mk(K->cam_ver[0], K->cam_ver[1], K->cam_ver[2]);
+        inv_w = K->inv_w; inv_h = K->inv_h; lens_radius = K->lens_radius; sample_offset = K->sample_offset; width = K->width;
+      }
+      // (the pixel's half of the key kept in a register per work item measured 0.8 % SLOWER on C2: a register more, a hash less)
+      S.rng.start(pcg((sample_offset + S.sample) ^ pcg((__umul24(S.py, width) + S.px) ^ seed_hash)));
+      float jx = S.rng.u01(), jy = S.rng.u01();
+      float sx = ((float)S.px + jx) * inv_w;
+      float sy = ((float)S.py + jy) * inv_h;
       V3 dir = ((cam_ll + cam_hor * sx) + cam_ver * sy) - cam_o;
-      ro = cam_o;
-      if (P.lens_radius > 0.0f) {
+      S.ro = cam_o;
+      if (lens_radius > 0.0f) {
         float a = 0.0f, b = 0.0f;
         bool found = false;
 #pragma unroll 1
         for (int i = 0; i < 8 && !found; i++) {
-          float ta = rng.u01() * 2.0f - 1.0f;
-          float tb = rng.u01() * 2.0f - 1.0f;
+          float ta = S.rng.u01() * 2.0f - 1.0f;
+          float tb = S.rng.u01() * 2.0f - 1.0f;
           if (ta * ta + tb * tb < 1.0f) { a = ta; b = tb; found = true; }
         }
-        float ra = a * P.lens_radius, rb = b * P.lens_radius;
-        V3 off = ld3(P.cam_u) * ra + ld3(P.cam_v) * rb;
-        ro = cam_o + off;
+        float ra = a * lens_radius, rb = b * lens_radius;
+        V3 off = mk(K->cam_u[0], K->cam_u[1], K->cam_u[2]) * ra + mk(K->cam_v[0], K->cam_v[1], K->cam_v[2]) * rb;
+        S.ro = cam_o + off;
         dir = dir - off;
       }
-      new_dir = dir;  // normalised in (3)
-      thr = mk(1.f, 1.f, 1.f);
-      bounce = 0;
-      alive = true;
+      S.new_dir = dir;  // normalised in (3)
+      S.thr = mk(1.f, 1.f, 1.f);
+      S.bounce = 0;
+      S.alive = true;
       n_paths++;
     }
     SECTION_END(c_gen);
 
     // ---- (3) start the traversal of every new segment --------------------------
-    if (alive && cur == kDone) {
-      rd = normalize(new_dir);
+    if (S.alive && S.cur == kDone) {
+      S.rd = normalize(S.new_dir);
       // |clamp_dir(d)| lies in [1e-30, 1] for every finite direction: inside rcp_fast's verified range
-      inv = mk(rcp_fast(clamp_dir(rd.x)), rcp_fast(clamp_dir(rd.y)), rcp_fast(clamp_dir(rd.z)));
-      noi = mk(-(ro.x * inv.x), -(ro.y * inv.y), -(ro.z * inv.z));
-      inv_xy = mk2(inv.x, inv.y); inv_zx = mk2(inv.z, inv.x); inv_yz = mk2(inv.y, inv.z);
-      noi_xy = mk2(noi.x, noi.y); noi_zx = mk2(noi.z, noi.x); noi_yz = mk2(noi.y, noi.z);
-      tbest = kTMax;
-      hit_ref = kDone;
-      cur = 0;  // root
-      stk.reset();
+      const V3 inv = mk(rcp_fast(clamp_dir(S.rd.x)), rcp_fast(clamp_dir(S.rd.y)), rcp_fast(clamp_dir(S.rd.z)));
+      const V3 noi = mk(-(S.ro.x * inv.x), -(S.ro.y * inv.y), -(S.ro.z * inv.z));
+      S.inv_xy = mk2(inv.x, inv.y); S.inv_zx = mk2(inv.z, inv.x); S.inv_yz = mk2(inv.y, inv.z);
+      S.noi_xy = mk2(noi.x, noi.y); S.noi_zx = mk2(noi.z, noi.x); S.noi_yz = mk2(noi.y, noi.z);
+      S.tbest = kTMax;
+      S.hit_ref = kDone;
+      S.cur = 0;  // root
+      S.stk.reset();
       n_rays++;
     }
-    if (DUAL) again = wave_count(q_alive ? qcur == kDone : !q_done) >= RTGPU_DUAL_PASS_MIN;
-    } while (DUAL && again);
-    // a parked ray owns the lane's stack: it goes back to the registers (slot P holds a fresh ray or nothing)
-    if (DUAL) swap_slots(qcur != kDone && qcur != 0u);
-    if (__ballot(alive || (DUAL && q_alive)) == 0ull) break;  // done implies !alive: the whole wave is dry
-
     SECTION_END(c_setup);
+    return S.alive;
+    };
+    bool any_alive = outer_sections(ray0);
+    if (R == 2) any_alive = outer_sections(ray1) || any_alive;
+    if (__ballot(any_alive) == 0ull) break;  // done implies !alive: the whole wave is dry
+
     // ---- (4) closest hit: ordered stack traversal (rows a3-a5) ------------------
-    // Every lane walks its own ray in the oracle's order; what the WAVE executes
-    // next is put to a vote between the lanes waiting at an inner node and the
-    // lanes waiting at a leaf: the node step runs while two thirds of the lanes
+    // Every lane walks its own ray(s) in the oracle's order; what the WAVE executes
+    // next is put to a vote between the rays waiting at an inner node and the
+    // rays waiting at a leaf: the node step runs while two thirds of the rays
     // wait for it, the leaf step otherwise (one popcount per step; measured best
-    // of 1/3, 2/5, 1/2, 3/5, 2/3, 3/4, 4/5, 7/8), the other lanes sit those steps out.  A plain while-while loop ran the node step for as few as
+    // of 1/3, 2/5, 1/2, 3/5, 2/3, 3/4, 4/5, 7/8), the other rays sit those steps out.  A plain while-while loop ran the node step for as few as
     // one lane (measured 13-27 % lane utilisation in the node step).
     // A leaf step tests ONE primitive and advances the reference in place
     // (first+1, count-1), so lanes with short leaves never wait for long ones.
     // The intersection tests are branch-free: a rejected candidate produces
     // values (possibly inf/NaN) that fail the final comparisons, exactly where
     // the oracle returns early.
+    // With R = 2 a step first REQUESTS what both rays of the lane need and then tests them one after the
+    // other: the second ray's LDS round trip runs under the first ray's arithmetic.
     // Scenes in LDS: waves in a traversal round issue ahead of waves in a shading pass (s_setprio 1 / 0).  The
     // round's steps are short dependent chains (LDS read -> slab test -> stack), the pass is long straight-line
     // code that fills any issue slot left: C2 3.74 -> 3.67 ms, C4's frame 212.2 -> 210.2 (2 and 3 measure the
     // same; the other way round 212.6).  Not on trees in memory: C3 18.22 -> 18.44 ms with it.
     if (SMALL) __builtin_amdgcn_s_setprio(RTGPU_PRIO_SMALL);
-    const int n_entry = wave_count(cur != kDone);
-    bool swapped = false;  // wave-uniform (MODE 8)
+    // rays of the wave for which pred holds (summed over the rays of a lane)
+#define RAYS_COUNT(expr) ([&]() __attribute__((always_inline)) { int n_; { const uint32_t c_ = ray0.cur; n_ = wave_count(expr); } \
+                                                                 if (R == 2) { const uint32_t c_ = ray1.cur; n_ += wave_count(expr); } return n_; }())
+    const int n_entry = RAYS_COUNT(c_ != kDone);
     for (;;) {
-      if (DUAL) {  // lanes that are through and hold a fresh ray in slot Q start it now
-        const bool can = cur == kDone && q_alive && qcur == 0u;
-        const int n_can = wave_count(can);
-        if (n_can >= RTGPU_DUAL_SWAP_MIN || (n_can > 0 && __ballot((int)cur != -1) == 0ull)) {
-          swap_slots(can);
-          swapped = true;
-        }
-      }
       // reference read as a signed int: inner node >= 0; leaf < -1; kDone == -1
-      const int n_trav = wave_count((int)cur != -1);
-      if (n_trav == 0 || (n_trav < (DUAL ? RTGPU_DUAL_REFILL : REFILL) && (n_trav < n_entry || swapped))) break;  // wave-uniform
-      int n_node = wave_count((int)cur >= 0);
-      if (STATS == 2) { wave_tick(lane, w_trav); if ((int)cur != -1) l_trav++; }
+      const int n_trav = RAYS_COUNT((int)c_ != -1);
+      if (n_trav == 0 || (n_trav < REFILL * R && n_trav < n_entry)) break;  // wave-uniform
+      int n_node = RAYS_COUNT((int)c_ >= 0);
+      if (STATS == 2) { wave_tick(lane, w_trav); if ((int)ray0.cur != -1) l_trav++; if (R == 2 && (int)ray1.cur != -1) l_trav++; }
       long long c_phase = STATS == 2 ? (long long)clock64() : 0;
       // the two votes as ONE scalar compare per step: a node step needs n_node > 0 and 3 n_node >= 2 n_trav,
       // i.e. n_node >= ceil(2 n_trav / 3) (>= 1 since n_trav >= 1); a leaf step 3 n_leaf > n_trav, i.e.
@@ -972,8 +969,13 @@ void trace_kernel(const KParams P) {
         do {
 #pragma unroll
           for (int unroll_ = 0; unroll_ < (SMALL ? RTGPU_NODE_UNROLL : 1); unroll_++) {
-          if (STATS == 2) { const int n_ = wave_count((int)cur != -1); if (lane == 0) t_node += (unsigned long long)n_; }
-          if (WIDE && (int)cur >= 0) {
+          if (STATS == 2) { const int n_ = RAYS_COUNT((int)c_ != -1); if (lane == 0) t_node += (unsigned long long)n_; }
+          if (WIDE && (int)ray0.cur >= 0) {
+            Ray &S = ray0;
+            uint32_t &cur = S.cur;
+            const f2 inv_xy = S.inv_xy, inv_zx = S.inv_zx, inv_yz = S.inv_yz, noi_xy = S.noi_xy, noi_zx = S.noi_zx, noi_yz = S.noi_yz;
+            const float tbest = S.tbest;
+            StackT &stk = S.stk;
             if (STATS == 2) wave_tick(lane, w_node);
             // 96-byte node at cur * 96 = (cur * 3) << 5: six loads, four children
             uint32_t c3;
@@ -1069,176 +1071,222 @@ void trace_kernel(const KParams P) {
 #undef RTGPU_CX
             cur = HYBRID ? stk.step4_hybrid(fast, n_hit, r0, r1, r2, r3, top) : stk.step4(n_hit, r0, r1, r2, r3, top);
           }
-          if (!WIDE && (int)cur >= 0) {
-            if (STATS == 2) wave_tick(lane, w_node);
-            const uint32_t top = stk.peek();
-            float4 q0, q1, q2, q3;
-            uint32_t c0, c1;
-            // MODE 0/1 (tree larger than the LDS cache) fetch every node through L1: a
-            // partial cache measured no gain on the big scenes and costs a
-            // test and two branches per step
-            if (SMALL) {
-              f4 w0 = node_cache[cur], w1 = node_cache[plane + cur], w2 = node_cache[2u * plane + cur],
-                 w3 = node_cache[3u * plane + cur];
-              q0 = make_float4(w0.x, w0.y, w0.z, w0.w);
-              q1 = make_float4(w1.x, w1.y, w1.z, w1.w);
-              q2 = make_float4(w2.x, w2.y, w2.z, w2.w);
-              q3 = make_float4(w3.x, w3.y, w3.z, w3.w);
-              c0 = __float_as_uint(q3.x); c1 = __float_as_uint(q3.y);
-            } else if (PACKED) {
-              // 48-byte node at cur * 48 = (cur * 3) << 4; the child references are the low
-              // bytes of q0's and q2's four planes, gathered with three v_perm_b32 each
-              uint32_t c3;
-              asm("v_lshl_add_u32 %0, %1, 1, %1" : "=v"(c3) : "v"(cur));
-              const float4 *n = (const float4 *)(nodes_base + (c3 << 4));
-              q0 = n[0]; q1 = n[1]; q2 = n[2];
-              q3 = q2;
-              const uint32_t a0 = __builtin_amdgcn_perm(__float_as_uint(q0.y), __float_as_uint(q0.x), 0x0C0C0400u);
-              const uint32_t b0 = __builtin_amdgcn_perm(__float_as_uint(q0.w), __float_as_uint(q0.z), 0x0C0C0400u);
-              c0 = __builtin_amdgcn_perm(b0, a0, 0x05040100u);
-              const uint32_t a1 = __builtin_amdgcn_perm(__float_as_uint(q2.y), __float_as_uint(q2.x), 0x0C0C0400u);
-              const uint32_t b1 = __builtin_amdgcn_perm(__float_as_uint(q2.w), __float_as_uint(q2.z), 0x0C0C0400u);
-              c1 = __builtin_amdgcn_perm(b1, a1, 0x05040100u);
+          if (!WIDE) {
+            // BVH2 node step in two halves, so that with R = 2 both rays' fetches are requested before either is tested
+            struct NodeData { float4 q0, q1, q2; uint32_t c0, c1, top; };
+            NodeData nd0, nd1;
+            auto node_fetch = [&](Ray &S, NodeData &D) __attribute__((always_inline)) {
+              const uint32_t cur = S.cur;
+              if (STATS == 2) wave_tick(lane, w_node);
+              D.top = S.stk.peek();
+              // MODE 0/1 (tree larger than the LDS cache) fetch every node through L1: a
+              // partial cache measured no gain on the big scenes and costs a
+              // test and two branches per step
+              if (SMALL) {
+                f4 w0 = node_cache[cur], w1 = node_cache[plane + cur], w2 = node_cache[2u * plane + cur],
+                   w3 = node_cache[3u * plane + cur];
+                D.q0 = make_float4(w0.x, w0.y, w0.z, w0.w);
+                D.q1 = make_float4(w1.x, w1.y, w1.z, w1.w);
+                D.q2 = make_float4(w2.x, w2.y, w2.z, w2.w);
+                D.c0 = __float_as_uint(w3.x); D.c1 = __float_as_uint(w3.y);
+              } else if (PACKED) {
+                // 48-byte node at cur * 48 = (cur * 3) << 4; the child references are the low
+                // bytes of q0's and q2's four planes, gathered with three v_perm_b32 each
+                uint32_t c3;
+                asm("v_lshl_add_u32 %0, %1, 1, %1" : "=v"(c3) : "v"(cur));
+                const float4 *n = (const float4 *)(nodes_base + (c3 << 4));
+                D.q0 = n[0]; D.q1 = n[1]; D.q2 = n[2];
+                const uint32_t a0 = __builtin_amdgcn_perm(__float_as_uint(D.q0.y), __float_as_uint(D.q0.x), 0x0C0C0400u);
+                const uint32_t b0 = __builtin_amdgcn_perm(__float_as_uint(D.q0.w), __float_as_uint(D.q0.z), 0x0C0C0400u);
+                D.c0 = __builtin_amdgcn_perm(b0, a0, 0x05040100u);
+                const uint32_t a1 = __builtin_amdgcn_perm(__float_as_uint(D.q2.y), __float_as_uint(D.q2.x), 0x0C0C0400u);
+                const uint32_t b1 = __builtin_amdgcn_perm(__float_as_uint(D.q2.w), __float_as_uint(D.q2.z), 0x0C0C0400u);
+                D.c1 = __builtin_amdgcn_perm(b1, a1, 0x05040100u);
+              } else {
+                const float4 *n = (const float4 *)(nodes_base + (cur << 6));  // 32-bit offset: < 4 GiB of nodes
+                D.q0 = n[0]; D.q1 = n[1]; D.q2 = n[2];
+                const float4 q3 = n[3];
+                D.c0 = __float_as_uint(q3.x); D.c1 = __float_as_uint(q3.y);
+              }
+              if (STATS) n_nodes++;
+            };
+            auto node_test = [&](Ray &S, const NodeData &D) __attribute__((always_inline)) {
+              const float4 q0 = D.q0, q1 = D.q1, q2 = D.q2;
+              // child 0: lo (q0.x q0.y q0.z) hi (q0.w q1.x q1.y); child 1: lo (q1.z q1.w q2.x) hi (q2.y q2.z q2.w)
+              // the twelve slab fmas as six v_pk_fma_f32 (two IEEE fmas per instruction,
+              // bit-identical to fmaf): the node's planes sit in memory in the pair order
+              // (x,y)(z,x)(y,z)(x,y)(z,x)(y,z), matched by the pre-paired 1/d and -(o/d)
+              f2 p0 = __builtin_elementwise_fma(mk2(q0.x, q0.y), S.inv_xy, S.noi_xy);  // lo0.x lo0.y
+              f2 p1 = __builtin_elementwise_fma(mk2(q0.z, q0.w), S.inv_zx, S.noi_zx);  // lo0.z hi0.x
+              f2 p2 = __builtin_elementwise_fma(mk2(q1.x, q1.y), S.inv_yz, S.noi_yz);  // hi0.y hi0.z
+              f2 p3 = __builtin_elementwise_fma(mk2(q1.z, q1.w), S.inv_xy, S.noi_xy);  // lo1.x lo1.y
+              f2 p4 = __builtin_elementwise_fma(mk2(q2.x, q2.y), S.inv_zx, S.noi_zx);  // lo1.z hi1.x
+              f2 p5 = __builtin_elementwise_fma(mk2(q2.z, q2.w), S.inv_yz, S.noi_yz);  // hi1.y hi1.z
+              float a0x = p0.x, a0y = p0.y, a0z = p1.x, a1x = p1.y, a1y = p2.x, a1z = p2.y;
+              float b0x = p3.x, b0y = p3.y, b0z = p4.x, b1x = p4.y, b1y = p5.x, b1z = p5.y;
+              // vmax_/vmin_: the bare instruction for the two operands that hipcc cannot
+              // prove canonical (tmin from the kernel arguments, tbest through the loop):
+              // the builtin costs an extra v_max x,x per operand per step
+              float tn0 = fmax_(fmax_(fmin_(a0x, a1x), fmin_(a0y, a1y)), vmax_(fmin_(a0z, a1z), tmin));
+              float tf0 = fmin_(fmin_(fmax_(a0x, a1x), fmax_(a0y, a1y)), vmin_(fmax_(a0z, a1z), S.tbest));
+              float tn1 = fmax_(fmax_(fmin_(b0x, b1x), fmin_(b0y, b1y)), vmax_(fmin_(b0z, b1z), tmin));
+              float tf1 = fmin_(fmin_(fmax_(b0x, b1x), fmax_(b0y, b1y)), vmin_(fmax_(b0z, b1z), S.tbest));
+              // an empty child (scenes of < 2 primitives) has its box at +inf and can
+              // never pass: tfar <= tbest <= FLT_MAX < tnear
+              bool h0 = tn0 <= tf0;
+              bool h1 = tn1 <= tf1;
+              // both hit: nearer first (tie: child 0), the other is pushed
+              bool swap = tn1 < tn0;
+              uint32_t near_c = (h0 && !(h1 && swap)) ? D.c0 : D.c1;
+              uint32_t far_c = swap ? D.c0 : D.c1;
+              S.cur = S.stk.step(h0 && h1, !(h0 || h1), near_c, far_c, D.top);
+            };
+            if (R == 1) {
+              if ((int)ray0.cur >= 0) { node_fetch(ray0, nd0); node_test(ray0, nd0); }
             } else {
-              const float4 *n = (const float4 *)(nodes_base + (cur << 6));  // 32-bit offset: < 4 GiB of nodes
-              q0 = n[0]; q1 = n[1]; q2 = n[2]; q3 = n[3];
-              c0 = __float_as_uint(q3.x); c1 = __float_as_uint(q3.y);
+              const bool at0 = (int)ray0.cur >= 0, at1 = (int)ray1.cur >= 0;
+              if (at0) node_fetch(ray0, nd0);
+              if (at1) node_fetch(ray1, nd1);
+              if (at0) node_test(ray0, nd0);
+              if (at1) node_test(ray1, nd1);
             }
-            if (STATS) n_nodes++;
-            // child 0: lo (q0.x q0.y q0.z) hi (q0.w q1.x q1.y); child 1: lo (q1.z q1.w q2.x) hi (q2.y q2.z q2.w)
-            // the twelve slab fmas as six v_pk_fma_f32 (two IEEE fmas per instruction,
-            // bit-identical to fmaf): the node's planes sit in memory in the pair order
-            // (x,y)(z,x)(y,z)(x,y)(z,x)(y,z), matched by the pre-paired 1/d and -(o/d)
-            f2 p0 = __builtin_elementwise_fma(mk2(q0.x, q0.y), inv_xy, noi_xy);  // lo0.x lo0.y
-            f2 p1 = __builtin_elementwise_fma(mk2(q0.z, q0.w), inv_zx, noi_zx);  // lo0.z hi0.x
-            f2 p2 = __builtin_elementwise_fma(mk2(q1.x, q1.y), inv_yz, noi_yz);  // hi0.y hi0.z
-            f2 p3 = __builtin_elementwise_fma(mk2(q1.z, q1.w), inv_xy, noi_xy);  // lo1.x lo1.y
-            f2 p4 = __builtin_elementwise_fma(mk2(q2.x, q2.y), inv_zx, noi_zx);  // lo1.z hi1.x
-            f2 p5 = __builtin_elementwise_fma(mk2(q2.z, q2.w), inv_yz, noi_yz);  // hi1.y hi1.z
-            float a0x = p0.x, a0y = p0.y, a0z = p1.x, a1x = p1.y, a1y = p2.x, a1z = p2.y;
-            float b0x = p3.x, b0y = p3.y, b0z = p4.x, b1x = p4.y, b1y = p5.x, b1z = p5.y;
-            // vmax_/vmin_: the bare instruction for the two operands that hipcc cannot
-            // prove canonical (tmin from the kernel arguments, tbest through the loop):
-            // the builtin costs an extra v_max x,x per operand per step
-            float tn0 = fmax_(fmax_(fmin_(a0x, a1x), fmin_(a0y, a1y)), vmax_(fmin_(a0z, a1z), tmin));
-            float tf0 = fmin_(fmin_(fmax_(a0x, a1x), fmax_(a0y, a1y)), vmin_(fmax_(a0z, a1z), tbest));
-            float tn1 = fmax_(fmax_(fmin_(b0x, b1x), fmin_(b0y, b1y)), vmax_(fmin_(b0z, b1z), tmin));
-            float tf1 = fmin_(fmin_(fmax_(b0x, b1x), fmax_(b0y, b1y)), vmin_(fmax_(b0z, b1z), tbest));
-            // an empty child (scenes of < 2 primitives) has its box at +inf and can
-            // never pass: tfar <= tbest <= FLT_MAX < tnear
-            bool h0 = tn0 <= tf0;
-            bool h1 = tn1 <= tf1;
-            // both hit: nearer first (tie: child 0), the other is pushed
-            bool swap = tn1 < tn0;
-            uint32_t near_c = (h0 && !(h1 && swap)) ? c0 : c1;
-            uint32_t far_c = swap ? c0 : c1;
-            cur = stk.step(h0 && h1, !(h0 || h1), near_c, far_c, top);
           }
           }
-          n_node = wave_count((int)cur >= 0);
+          n_node = RAYS_COUNT((int)c_ >= 0);
         } while (n_node >= node_quorum);
         if (STATS == 2) c_nodes += (long long)clock64() - c_phase;
       } else {
         int n_leaf;
         do {
-          if (STATS == 2) { const int n_ = wave_count((int)cur != -1); if (lane == 0) t_leaf += (unsigned long long)n_; }
-          const bool at_leaf = (int)cur < -1;
-          const bool at_sph = at_leaf && (cur & RTGPU_REF_SPHERE);
-          const bool at_tri = at_leaf && !(cur & RTGPU_REF_SPHERE);
-          const uint32_t i = RTGPU_REF_FIRST(cur);
-          bool fast = true;
-          const uint32_t top = HYBRID ? stk.peek_hybrid(fast) : stk.peek();
-          if (at_sph) {
-            float4 s;
-            if (sph_in_lds) { const f4 w = sph_cache[i]; s = make_float4(w.x, w.y, w.z, w.w); }
-            else s = *(const float4 *)(sphs_base + (i << 4));
-            if (STATS) n_sphs++;
-            if (STATS == 2) wave_tick(lane, w_sph);
-            V3 oc = ro - mk(s.x, s.y, s.z);
-            float hb = dot(oc, rd);
-            float cc = dot(oc, oc) - (TINY ? s.w : s.w * s.w);
-            float disc = hb * hb - cc;
-            float sq = sqrt_exact(disc);  // NaN for a negative discriminant: fails every test below
-            float t = -hb - sq;
-            bool ok = t > tmin && t < tbest;
-            float t2 = -hb + sq;
-            bool ok2 = t2 > tmin && t2 < tbest;
-            t = ok ? t : t2;
-            if (ok || ok2) { tbest = t; hit_ref = cur; }
-          }
-          // a lane tests up to kTriStep of the triangles left in its leaf per step (all
-          // records requested before the first test): same tests in the same order, fewer
-          // dependent round trips
-          const uint32_t left = (cur >> 27) & 7u;                                    // triangles after this one
-          const uint32_t more = TRIS > 1 && at_tri ? (left < (uint32_t)(TRIS - 1) ? left : (uint32_t)(TRIS - 1)) : 0u;
-          if (at_tri) {
-            // i * 48 as (i * 3) << 4 with the * 3 spelled as one v_lshl_add_u32: hipcc turns any
-            // C spelling back into v_mul_lo_u32, which is quarter rate.  32-bit offset: < 4 GiB of triangles
-            uint32_t i3;
-            asm("v_lshl_add_u32 %0, %1, 1, %1" : "=v"(i3) : "v"(i));
-            const float4 *tp = (const float4 *)(tris_base + (i3 << 4));
-            float4 rec[TRIS][3];
+          if (STATS == 2) { const int n_ = RAYS_COUNT((int)c_ != -1); if (lane == 0) t_leaf += (unsigned long long)n_; }
+          // leaf step in two halves like the node step
+          struct LeafData { bool at_leaf, at_sph, at_tri, fast; uint32_t i, top, left, more; float4 s; float4 rec[TRIS][3]; };
+          LeafData ld0, ld1;
+          auto leaf_fetch = [&](Ray &S, LeafData &D) __attribute__((always_inline)) {
+            const uint32_t cur = S.cur;
+            D.at_leaf = (int)cur < -1;
+            D.at_sph = D.at_leaf && (cur & RTGPU_REF_SPHERE);
+            D.at_tri = D.at_leaf && !(cur & RTGPU_REF_SPHERE);
+            D.i = RTGPU_REF_FIRST(cur);
+            D.fast = true;
+            D.top = HYBRID ? S.stk.peek_hybrid(D.fast) : S.stk.peek();
+            // a lane tests up to kTriStep of the triangles left in its leaf per step (all
+            // records requested before the first test): same tests in the same order, fewer
+            // dependent round trips
+            D.left = (cur >> 27) & 7u;                                    // triangles after this one
+            D.more = TRIS > 1 && D.at_tri ? (D.left < (uint32_t)(TRIS - 1) ? D.left : (uint32_t)(TRIS - 1)) : 0u;
+          };
+          auto sph_fetch = [&](Ray &S, LeafData &D) __attribute__((always_inline)) {
+            if (D.at_sph) {
+              if (sph_in_lds) { const f4 w = sph_cache[D.i]; D.s = make_float4(w.x, w.y, w.z, w.w); }
+              else D.s = *(const float4 *)(sphs_base + (D.i << 4));
+            }
+          };
+          auto sph_test = [&](Ray &S, LeafData &D) __attribute__((always_inline)) {
+            if (D.at_sph) {
+              const float4 s = D.s;
+              if (STATS) n_sphs++;
+              if (STATS == 2) wave_tick(lane, w_sph);
+              V3 oc = S.ro - mk(s.x, s.y, s.z);
+              float hb = dot(oc, S.rd);
+              float cc = dot(oc, oc) - (TINY ? s.w : s.w * s.w);
+              float disc = hb * hb - cc;
+              float sq = sqrt_exact(disc);  // NaN for a negative discriminant: fails every test below
+              float t = -hb - sq;
+              bool ok = t > tmin && t < S.tbest;
+              float t2 = -hb + sq;
+              bool ok2 = t2 > tmin && t2 < S.tbest;
+              t = ok ? t : t2;
+              if (ok || ok2) { S.tbest = t; S.hit_ref = S.cur; }
+            }
+          };
+          auto tri_fetch = [&](Ray &S, LeafData &D) __attribute__((always_inline)) {
+            if (D.at_tri) {
+              // i * 48 as (i * 3) << 4 with the * 3 spelled as one v_lshl_add_u32: hipcc turns any
+              // C spelling back into v_mul_lo_u32, which is quarter rate.  32-bit offset: < 4 GiB of triangles
+              uint32_t i3;
+              asm("v_lshl_add_u32 %0, %1, 1, %1" : "=v"(i3) : "v"(D.i));
+              const float4 *tp = (const float4 *)(tris_base + (i3 << 4));
 #pragma unroll
-            for (int k = 0; k < TRIS; k++) {
-              // a lane with fewer triangles left re-reads its last one (never past the array)
-              if (TINY) {
-                const uint32_t j3 = i3 + 3u * ((uint32_t)k < more ? (uint32_t)k : more);
-                const f4 a = tri_cache[j3], b = tri_cache[j3 + 1u], c = tri_cache[j3 + 2u];
-                rec[k][0] = make_float4(a.x, a.y, a.z, a.w); rec[k][1] = make_float4(b.x, b.y, b.z, b.w);
-                rec[k][2] = make_float4(c.x, c.y, c.z, c.w);
-              } else if (k == 0) {
-                rec[0][0] = tp[0]; rec[0][1] = tp[1]; rec[0][2] = tp[2];
-              } else {
-                // Only lanes that HAVE a k-th triangle left request it: the vector memory pipeline charges a load by
-                // its active lanes (~0.7 cycle per lane and 16 bytes, tools/ubench/l1_td.hip), and on a fine mesh most
-                // leaves hold one triangle - re-reading the last record in the other lanes (what this did before)
-                // was a tenth of all the lane-loads of the S1 frame.  The loads of all k are still in flight together.
-                rec[k][0] = rec[k][1] = rec[k][2] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if ((uint32_t)k <= more) {
-                  const float4 *tq = tp + 3u * (uint32_t)k;
-                  rec[k][0] = tq[0]; rec[k][1] = tq[1]; rec[k][2] = tq[2];
+              for (int k = 0; k < TRIS; k++) {
+                if (TINY) {
+                  // a lane with fewer triangles left re-reads its last one (never past the array)
+                  const uint32_t j3 = i3 + 3u * ((uint32_t)k < D.more ? (uint32_t)k : D.more);
+                  const f4 a = tri_cache[j3], b = tri_cache[j3 + 1u], c = tri_cache[j3 + 2u];
+                  D.rec[k][0] = make_float4(a.x, a.y, a.z, a.w); D.rec[k][1] = make_float4(b.x, b.y, b.z, b.w);
+                  D.rec[k][2] = make_float4(c.x, c.y, c.z, c.w);
+                } else if (k == 0) {
+                  D.rec[0][0] = tp[0]; D.rec[0][1] = tp[1]; D.rec[0][2] = tp[2];
+                } else {
+                  // Only lanes that HAVE a k-th triangle left request it: the vector memory pipeline charges a load by
+                  // its active lanes (~0.7 cycle per lane and 16 bytes, tools/ubench/l1_td.hip), and on a fine mesh most
+                  // leaves hold one triangle - re-reading the last record in the other lanes (what this did before)
+                  // was a tenth of all the lane-loads of the S1 frame.  The loads of all k are still in flight together.
+                  D.rec[k][0] = D.rec[k][1] = D.rec[k][2] = make_float4(0.f, 0.f, 0.f, 0.f);
+                  if ((uint32_t)k <= D.more) {
+                    const float4 *tq = tp + 3u * (uint32_t)k;
+                    D.rec[k][0] = tq[0]; D.rec[k][1] = tq[1]; D.rec[k][2] = tq[2];
+                  }
                 }
               }
             }
-            if (STATS) n_tris += 1u + more;
-            if (STATS == 2) wave_tick(lane, w_tri);
+          };
+          auto tri_test = [&](Ray &S, LeafData &D) __attribute__((always_inline)) {
+            if (D.at_tri) {
+              if (STATS) n_tris += 1u + D.more;
+              if (STATS == 2) wave_tick(lane, w_tri);
 #pragma unroll
-            for (int k = 0; k < TRIS; k++) {
-              if (k == 0 || (uint32_t)k <= more) {
-                const float4 a = rec[k][0], b = rec[k][1], c = rec[k][2];
-                V3 v0 = mk(a.x, a.y, a.z), e1 = mk(b.x, b.y, b.z), e2 = mk(c.x, c.y, c.z);
-                V3 pvec = cross(rd, e2);
-                float det = dot(e1, pvec);
-                bool valid = !(__builtin_fabsf(det) < 1e-30f);
-                float inv_det = rcp_exact(det);
-                V3 tvec = ro - v0;
-                float u = dot(tvec, pvec) * inv_det;
-                valid = valid && !(u < 0.0f || u > 1.0f);
-                V3 qvec = cross(tvec, e1);
-                float v = dot(rd, qvec) * inv_det;
-                valid = valid && !(v < 0.0f || u + v > 1.0f);
-                float t = dot(e2, qvec) * inv_det;
-                // the leaf cursor as it stands at this test: first + k, count - k
-                if (valid && t > tmin && t < tbest) {
-                  tbest = t;
-                  hit_ref = cur + (uint32_t)k - ((uint32_t)k << 27);
-                  hit_mat = __float_as_uint(b.w);
-                  if (KEEP_N) { hit_n = cross(e1, e2); hit_prim = __float_as_uint(a.w); }
+              for (int k = 0; k < TRIS; k++) {
+                if (k == 0 || (uint32_t)k <= D.more) {
+                  const float4 a = D.rec[k][0], b = D.rec[k][1], c = D.rec[k][2];
+                  V3 v0 = mk(a.x, a.y, a.z), e1 = mk(b.x, b.y, b.z), e2 = mk(c.x, c.y, c.z);
+                  V3 pvec = cross(S.rd, e2);
+                  float det = dot(e1, pvec);
+                  bool valid = !(__builtin_fabsf(det) < 1e-30f);
+                  float inv_det = rcp_exact(det);
+                  V3 tvec = S.ro - v0;
+                  float u = dot(tvec, pvec) * inv_det;
+                  valid = valid && !(u < 0.0f || u > 1.0f);
+                  V3 qvec = cross(tvec, e1);
+                  float v = dot(S.rd, qvec) * inv_det;
+                  valid = valid && !(v < 0.0f || u + v > 1.0f);
+                  float t = dot(e2, qvec) * inv_det;
+                  // the leaf cursor as it stands at this test: first + k, count - k
+                  if (valid && t > tmin && t < S.tbest) {
+                    S.tbest = t;
+                    S.hit_ref = S.cur + (uint32_t)k - ((uint32_t)k << 27);
+                    S.hit_mat = __float_as_uint(b.w);
+                    if (KEEP_N) { S.hit_n = cross(e1, e2); S.hit_prim = __float_as_uint(a.w); }
+                  }
                 }
               }
             }
+          };
+          auto leaf_advance = [&](Ray &S, LeafData &D) __attribute__((always_inline)) {
+            if (D.at_leaf) {
+              const bool last_now = D.left == D.more;
+              uint32_t next = S.cur + (D.more + 1u) - ((D.more + 1u) << 27);  // first+1, count-1 per test
+              uint32_t popped = HYBRID ? S.stk.pop_if_hybrid(D.fast, last_now, D.top) : S.stk.pop_if(last_now, D.top);
+              S.cur = last_now ? popped : next;
+            }
+          };
+          if (R == 1) {
+            leaf_fetch(ray0, ld0);
+            sph_fetch(ray0, ld0); sph_test(ray0, ld0);
+            tri_fetch(ray0, ld0); tri_test(ray0, ld0);
+            leaf_advance(ray0, ld0);
+          } else {
+            leaf_fetch(ray0, ld0); sph_fetch(ray0, ld0); tri_fetch(ray0, ld0);
+            leaf_fetch(ray1, ld1); sph_fetch(ray1, ld1); tri_fetch(ray1, ld1);
+            sph_test(ray0, ld0); tri_test(ray0, ld0); leaf_advance(ray0, ld0);
+            sph_test(ray1, ld1); tri_test(ray1, ld1); leaf_advance(ray1, ld1);
           }
-          if (at_leaf) {
-            const bool last_now = left == more;
-            uint32_t next = cur + (more + 1u) - ((more + 1u) << 27);  // first+1, count-1 per test
-            uint32_t popped = HYBRID ? stk.pop_if_hybrid(fast, last_now, top) : stk.pop_if(last_now, top);
-            cur = last_now ? popped : next;
-          }
-          n_leaf = wave_count((int)cur < -1);
+          n_leaf = RAYS_COUNT((int)c_ < -1);
         } while (n_leaf >= leaf_quorum);
         if (STATS == 2) c_leaves += (long long)clock64() - c_phase;
       }
     }
+#undef RAYS_COUNT
     if (SMALL) __builtin_amdgcn_s_setprio(0);
     SECTION_END(c_trav);
   }
@@ -1266,7 +1314,7 @@ void trace_kernel(const KParams P) {
   if (STATS == 2) {
     unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
     if (lane == 0) {
-      size_t w = ((size_t)blockIdx.x * kBlock + tid) >> 6;
+      size_t w = ((size_t)blockIdx.x * BLOCK + tid) >> 6;
       P.wave_times[w * 4 + 0] = t_start;
       P.wave_times[w * 4 + 1] = t_end;
       P.wave_times[w * 4 + 2] = t_dry;
@@ -1290,12 +1338,9 @@ void trace_kernel(const KParams P) {
     {  // MODE 5: lanes in node steps, of them served from the LDS copy of the top; steps on the slow stack path
       unsigned long long a = wave_sum(l_node), b = wave_sum(l_cached), c = wave_sum(w_slow);
       if (lane == 0) { atomicAdd(&P.counters[23], a); atomicAdd(&P.counters[24], b); atomicAdd(&P.counters[25], c); }
-      // lanes still traversing (at a node or a leaf), summed over node steps / leaf steps of the wave
+      // rays still traversing (at a node or a leaf), summed over node steps / leaf steps of the wave
       unsigned long long d = wave_sum(t_node), e = wave_sum(t_leaf);
       if (lane == 0) { atomicAdd(&P.counters[26], d); atomicAdd(&P.counters[27], e); }
-      // MODE 8: slot exchanges of a wave, lanes that took part
-      unsigned long long f = wave_sum(w_swap), g = wave_sum(l_swap);
-      if (lane == 0) { atomicAdd(&P.counters[28], f); atomicAdd(&P.counters[29], g); }
     }
   }
 }
@@ -1448,7 +1493,7 @@ struct rtgpu_ctx {
   int variant = 0;              // index into kVariants (refill threshold), see rtgpu_create
   int stack_lds = kStackLds;    // cap on LDS stack entries (RTGPU_STACK_LDS shrinks it for tests)
   bool no_node_cache = false;   // RTGPU_NO_NODE_CACHE=1: every node through the vector L1 (experiments)
-  bool dual = false;            // RTGPU_DUAL=1: MODE 8 instead of 7 (experiment)
+  int rays2 = -1;               // RTGPU_RAYS2=0/1: MODE 8 (two rays per lane in lock step) instead of 7; -1: the default (kRays2Default)
   bool no_mats_cache = false;   // RTGPU_NO_MATS_CACHE=1: trees in memory read materials through L1 (experiments)
   bool no_tiny = false;         // RTGPU_NO_TINY=1: a scene that fits LDS whole still runs MODE 2 (experiments)
   bool no_sphere_cache = false; // RTGPU_NO_SPHERE_CACHE=1: MODE 2 reads spheres through L1 as before (experiments)
@@ -1484,12 +1529,11 @@ namespace {
 // code path; the threshold only changes WHEN finished lanes are refilled, never
 // what a path computes.  RTGPU_REFILL (0/20/40) selects it for experiments.
 using KernelFn = void (*)(const KParams);
-constexpr int kModes = 11;
-struct Variant { int refill; KernelFn fn[3][kModes]; };  // [plain, stats, profile][MODE 0..10 of trace_kernel]
+constexpr int kModes = 9;
+struct Variant { int refill; KernelFn fn[3][kModes]; };  // [plain, stats, profile][MODE 0..8 of trace_kernel]
 #define RTGPU_VARIANT_ROW(S, R)                                                                         \
   {trace_kernel<S, R, 0>, trace_kernel<S, R, 1>, trace_kernel<S, R, 2>, trace_kernel<S, R, 3>, trace_kernel<S, R, 4>, \
-   trace_kernel<S, R, 5>, trace_kernel<S, R, 6>, trace_kernel<S, R, 7>, trace_kernel<S, R, 8>, \
-   trace_kernel<S, R, 9>, trace_kernel<S, R, 10>}
+   trace_kernel<S, R, 5>, trace_kernel<S, R, 6>, trace_kernel<S, R, 7>, trace_kernel<S, R, 8>}
 #define RTGPU_VARIANT(R) {R, {RTGPU_VARIANT_ROW(0, R), RTGPU_VARIANT_ROW(1, R), RTGPU_VARIANT_ROW(2, R)}}
 #ifndef RTGPU_REFILL_SMALL
 #define RTGPU_REFILL_SMALL 20
@@ -1503,6 +1547,10 @@ const Variant kVariants[] = {RTGPU_VARIANT(0), RTGPU_VARIANT(RTGPU_REFILL_SMALL)
 // the traversal loop late); 40 where nodes come from memory and the time follows the
 // number of dependent steps a ray takes (so keep the lanes of a step together; measured 16 / 32 / 40 / 48 / 56).
 constexpr int kVariantSmallTree = 1, kVariantLargeTree = 2;
+#ifndef RTGPU_RAYS2_DEFAULT
+#define RTGPU_RAYS2_DEFAULT 0
+#endif
+constexpr bool kRays2Default = RTGPU_RAYS2_DEFAULT != 0;  // MODE 8 for scenes that fit LDS whole (RTGPU_RAYS2 overrides)
 
 bool hip_fail(rtgpu_ctx *ctx, hipError_t e, const char *what) {
   if (e == hipSuccess) return false;
@@ -1621,7 +1669,7 @@ extern "C" int rtgpu_create(rtgpu_ctx **out, int device_index) {
   if (const char *env = std::getenv("RTGPU_WIDE_CACHE")) ctx->wide_cache = std::atoi(env) != 0;
   if (const char *env = std::getenv("RTGPU_NO_SPHERE_CACHE")) ctx->no_sphere_cache = std::atoi(env) != 0;
   if (const char *env = std::getenv("RTGPU_NO_TINY")) ctx->no_tiny = std::atoi(env) != 0;
-  if (const char *env = std::getenv("RTGPU_DUAL")) ctx->dual = std::atoi(env) != 0;
+  if (const char *env = std::getenv("RTGPU_RAYS2")) ctx->rays2 = std::atoi(env) != 0 ? 1 : 0;
   if (const char *env = std::getenv("RTGPU_NO_MATS_CACHE")) ctx->no_mats_cache = std::atoi(env) != 0;
   if (const char *env = std::getenv("RTGPU_STACK_LDS")) {
     int want = std::atoi(env);
@@ -2125,9 +2173,6 @@ int launch_frame(rtgpu_ctx *ctx, const rtgpu_camera *cam, const rtgpu_settings *
   // that may not use the context's overflow buffer, nor with RTGPU_WIDE_CACHE=0 (experiments).
   const bool wide_cache = wide && ctx->wide_cache && sc.may_allocate && kBlocksPerCU == 1;
   if (wide_cache) stack_fit = (uint32_t)((kLdsBytes - kWideCached * (int)sizeof(rtgpu_node4)) / (kBlock * sizeof(uint32_t)));
-  // experiment (RTGPU_DUAL=1): two work items per lane over a four-wide tree; the records take 32 KiB of the stacks' LDS
-  const bool wide_dual = wide && !wide_cache && ctx->dual && sc.may_allocate && kBlocksPerCU == 1;
-  if (wide_dual) stack_fit = (uint32_t)((kLdsBytes - 2 * 16 * kBlock) / (kBlock * sizeof(uint32_t)));
   if (stack_lds > stack_fit) stack_lds = stack_fit;
   P.stack_lds = stack_lds;
   P.stack_lds_only = (need <= stack_lds && !wide_cache) ? 1u : 0u;
@@ -2159,9 +2204,12 @@ int launch_frame(rtgpu_ctx *ctx, const rtgpu_camera *cam, const rtgpu_settings *
       P.sph_cached = (uint32_t)ctx->host.n_spheres;
       P.tiny_tris = (uint32_t)ctx->host.n_tris;
       lds_bytes = stack_bytes + (size_t)kTinyEnd * 16;
-      if (ctx->dual && lds_bytes + 2u * 16u * kBlock <= (size_t)kLdsBytes) {  // experiment: two work items per lane
+      // two rays per lane in lock step (MODE 8): blocks of kBlock2 threads, two stacks per lane
+      const bool rays2 = ctx->rays2 >= 0 ? ctx->rays2 != 0 : kRays2Default;
+      const size_t stack_bytes2 = (size_t)stack_lds * 2u * kBlock2 * sizeof(uint32_t);
+      if (rays2 && stack_bytes2 + (size_t)kTinyEnd * 16 <= (size_t)kLdsBytes) {
         mode = 8;
-        lds_bytes += 2u * 16u * kBlock;
+        lds_bytes = stack_bytes2 + (size_t)kTinyEnd * 16;
       }
     }
   }
@@ -2169,15 +2217,11 @@ int launch_frame(rtgpu_ctx *ctx, const rtgpu_camera *cam, const rtgpu_settings *
     if (mode == 2 || mode >= 7) { ctx->err = "internal: packed nodes on a tree that fits the LDS cache"; return 2; }
     mode += wide ? 5 : 3;
   }
-  if (wide_dual) {  // mode 5 (deeper stack entries in memory) or 6
-    mode = mode == 6 ? 9 : 10;
-    lds_bytes += 2u * 16u * kBlock;
-  }
   if (wide_cache) {  // mode == 5
     P.n_cached = (uint32_t)(ctx->host.n_nodes4 < (uint64_t)kWideCached ? ctx->host.n_nodes4 : (uint64_t)kWideCached);
     lds_bytes = stack_bytes + (size_t)kWideCached * sizeof(rtgpu_node4);
   }
-  if (mode != 2 && mode != 7 && mode != 8 && !wide_dual && !ctx->no_mats_cache && ctx->host.n_materials > 0 &&
+  if (mode != 2 && mode != 7 && mode != 8 && !ctx->no_mats_cache && ctx->host.n_materials > 0 &&
       ctx->host.n_materials <= (uint64_t)kLdsMats && kBlocksPerCU == 1) {
     const size_t mb = (size_t)ctx->host.n_materials * sizeof(rtgpu_material);
     if (lds_bytes + mb > (size_t)kLdsBytes && !P.stack_lds_only && sc.may_allocate && P.stack_lds > 8u) {
@@ -2195,7 +2239,9 @@ int launch_frame(rtgpu_ctx *ctx, const rtgpu_camera *cam, const rtgpu_settings *
   HIP_TRY(ctx, hipMemsetAsync(sc.counters, 0, kCounterBytes, stream));
   ctx->timed = false;
   if (n_items > 0) {
-    uint64_t want = (n_items + kBlock - 1) / kBlock;
+    const unsigned block = mode == 8 ? (unsigned)kBlock2 : (unsigned)kBlock;
+    const uint64_t per_block = mode == 8 ? 2ull * kBlock2 : (uint64_t)kBlock;   // work items a block holds at a time
+    uint64_t want = (n_items + per_block - 1) / per_block;
     uint64_t cap = (uint64_t)ctx->num_cus * (uint64_t)ctx->blocks_per_cu[want_stats ? 1 : 0];
     unsigned grid = (unsigned)(want < cap ? want : cap);
     if ((size_t)grid * kBlock > ctx->ovf_threads) { ctx->err = "internal: grid exceeds the overflow stack"; return 2; }
@@ -2205,7 +2251,7 @@ int launch_frame(rtgpu_ctx *ctx, const rtgpu_camera *cam, const rtgpu_settings *
     const int inst = (s->flags & RTGPU_FLAG_PROFILE) ? 2 : want_stats ? 1 : 0;
     KernelFn fn = var.fn[inst][mode];
     std::snprintf(ctx->kernel_name, sizeof(ctx->kernel_name), "trace_kernel<%d,%d,%d>", inst, var.refill, mode);
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), lds_bytes, stream, P);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(block), lds_bytes, stream, P);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev1, stream));
     ctx->timed = true;

@@ -81,3 +81,34 @@ def test_static_scratch_entry_point(ra, oracle):
                 ctx.render_device_static(cam_d, st, acc.data_ptr())
     finally:
         ctx.close()
+
+
+def test_static_entry_point_under_graph_capture(ra):
+    """The use include/rtgpu.h names first: the call captured into a HIP graph (nothing in it allocates, so the
+    capture is legal) and the graph replayed - every replay writes the frame rtgpu_render_device writes."""
+    import torch
+    ctx = ra.Context(0)
+    try:
+        scene, cam = ra.Scene.builtin(0, aspect=16 / 9)
+        ctx.upload(scene)
+        w, h = 640, 360
+        st = ra.default_settings(w, h, spp=4, max_depth=8)              # two chunks of two samples: planes + combine_kernel
+        want = torch.zeros((w * h, 4), dtype=torch.float32, device="cuda")
+        ctx.render_device(cam, st, want.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        out = torch.zeros((w * h, 4), dtype=torch.float32, device="cuda")
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            ctx.render_device_static(cam, st, out.data_ptr(), None, side.cuda_stream)     # warm-up on the capture stream
+        side.synchronize()
+        assert torch.equal(out.view(torch.int32), want.view(torch.int32))
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            ctx.render_device_static(cam, st, out.data_ptr(), None, side.cuda_stream)
+        for k in range(3):
+            out.fill_(float(k + 5))
+            g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(out.view(torch.int32), want.view(torch.int32)), f"replay {k}"
+    finally:
+        ctx.close()

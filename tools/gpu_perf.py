@@ -15,6 +15,7 @@ CONFIGS = {
     "c5": (2, 7, 1920, 1080, 4, 8),     # S2 at level 7 = 2.6M tris (level 8 = 10.5M)
     "c5full": (2, 8, 1920, 1080, 4, 8),
     "c3full": (1, 8, 1920, 1080, 64, 8),   # C3 as BASELINE.json states it
+    "c5full16": (2, 8, 1920, 1080, 16, 8), # C5's frame as BASELINE.json states it (16 spp), on ONE GPU
     "c4": (0, 0, 3840, 2160, 256, 8),      # C4's frame on ONE GPU (its 2/4/8-GPU runs are the driver's)
     "c2lens": (0, 0, 1920, 1080, 16, 8, 0.1),  # C2 through the thin lens (aperture 0.1)
 }

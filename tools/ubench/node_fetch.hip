@@ -67,9 +67,9 @@ int main() {
       {"oct/record   1x16B of 128B", 8, 1, 128, k<8, 1, 128, 0>, k<8, 1, 128, 20>, 20},
   };
   for (int fill = 1; fill < 2; fill++)
-    for (int log2_bytes : {14, 19, 21, 23, 25, 27, 29}) {   // 16 KB (L1), 2 MB (L2), 32 MB (L2 of 8 XCDs / MALL), 512 MB (HBM)
+    for (int log2_bytes : {14, 21, 23, 25, 29}) {   // 16 KB (L1), 2 MB (one L2), 8 MB, 32 MB (the eight L2s / Infinity Cache), 512 MB (HBM)
       for (const Case &c : cases)
-        for (int blocks_per_cu : {4}) {
+        for (int blocks_per_cu : {1, 4, 6}) {
           uint32_t n_rec = 1; while ((size_t)n_rec * 2 * c.rec <= (1ull << log2_bytes)) n_rec *= 2;
           const int iters = log2_bytes >= 25 ? 300 : 800;
           auto launch = [&]() { hipLaunchKernelGGL(fill ? c.fn1 : c.fn0, dim3(cus * blocks_per_cu), dim3(256), 0, 0, tab, n_rec - 1, iters, out); };
