@@ -409,6 +409,11 @@ __device__ __forceinline__ void wave_tick(unsigned lane, unsigned long long &c) 
 // behind the other's arithmetic.  12 waves x 2 rays are 24 dependent chains per CU where 16 waves
 // x 1 ray are 16, with ONE copy of the scene in LDS (24 waves of one ray each would need two blocks
 // per CU and two copies, which do not fit).  Per ray the operations are exactly those of mode 7.
+// 9 and 10: as 5 and 6 with every four-wide node in a 128-BYTE SLOT of the device copy (the 96 bytes of the format, 32 of
+// padding): a node is then ONE line for the L2 and the fabric instead of 1.5 on average.  For trees far larger than the
+// caches (S2 level 8: 0.4 GB of nodes, L2 hit rate 0.57, the fabric at 5.2 TB/s) the lines are what the launch waits for;
+// for trees that live in L1 / L2 the aligned slots cost more than they save (every lane of a load reads the same 16 bytes of
+// its line: bank conflicts), so the host chooses by the size of the tree.
 // (The slot-exchange experiment of round 2 - modes 8-10 then, profiles/r02/experiments.txt H and J -
 // was a measured negative and is gone from the source.)
 template <int STATS, int REFILL, int MODE>
@@ -416,9 +421,10 @@ __global__ __launch_bounds__(MODE == 8 ? kBlock2 : kBlock)
 __attribute__((amdgpu_waves_per_eu(MODE == 8 ? kBlock2 * RTGPU_BLOCKS_PER_CU / 256 : RTGPU_WAVES_PER_EU,
                                    MODE == 8 ? kBlock2 * RTGPU_BLOCKS_PER_CU / 256 : RTGPU_WAVES_PER_EU)))
 void trace_kernel(const KParams P) {
-  constexpr bool LDS_ONLY = MODE == 1 || MODE == 2 || MODE == 4 || MODE == 6 || MODE == 7 || MODE == 8, SMALL = MODE == 2 || MODE == 7 || MODE == 8,
+  constexpr bool LDS_ONLY = MODE == 1 || MODE == 2 || MODE == 4 || MODE == 6 || MODE == 7 || MODE == 8 || MODE == 10, SMALL = MODE == 2 || MODE == 7 || MODE == 8,
                  TINY = MODE == 7 || MODE == 8, PACKED = MODE == 3 || MODE == 4,
-                 WIDE = MODE == 5 || MODE == 6, HYBRID = MODE == 5;
+                 WIDE = MODE == 5 || MODE == 6 || MODE == 9 || MODE == 10, HYBRID = MODE == 5 || MODE == 9,
+                 SLOT128 = MODE == 9 || MODE == 10;
   constexpr int R = MODE == 8 ? 2 : 1;                  // rays a lane traverses in lock step
   constexpr int BLOCK = MODE == 8 ? kBlock2 : kBlock;   // threads per block
   constexpr int STRIDE = BLOCK * R;                     // words between consecutive entries of one stack
@@ -977,10 +983,19 @@ void trace_kernel(const KParams P) {
             const float tbest = S.tbest;
             StackT &stk = S.stk;
             if (STATS == 2) wave_tick(lane, w_node);
-            // 96-byte node at cur * 96 = (cur * 3) << 5: six loads, four children
+            // 96-byte node at cur * 96 = (cur * 3) << 5 (or in its 128-byte slot at cur << 7): six loads, four children
             uint32_t c3;
             asm("v_lshl_add_u32 %0, %1, 1, %1" : "=v"(c3) : "v"(cur));
-            const float4 *n = (const float4 *)(nodes_base + (c3 << 5));
+            const uint32_t node_off = SLOT128 ? cur << 7 : c3 << 5;
+            // 128-byte slots: every lane of a load would read the SAME 16 bytes of its line (bank conflicts in the L1), so
+            // odd nodes fetch their two halves (children 0,1 | children 2,3: identical code below) the other way round and
+            // the child numbers in the sort keys are turned back (sw2): two bank positions per load instead of one
+            // ... and nodes with bit 1 set sit 32 bytes into their slot (pad_nodes4_kernel): four positions in all, as many as the
+            // 96-byte stride gives
+            const uint32_t sw = SLOT128 ? (cur & 1u) : 0u, sw2 = sw << 1;
+            const uint32_t slot_off = SLOT128 ? node_off + ((cur & 2u) << 4) : node_off;
+            const uint32_t off_a = SLOT128 ? slot_off + sw * 48u : node_off, off_b = SLOT128 ? slot_off + 48u - sw * 48u : node_off + 48u;
+            const float4 *n = (const float4 *)(nodes_base + off_a), *n2 = (const float4 *)(nodes_base + off_b);
             bool fast = true;
             const uint32_t top = HYBRID ? stk.peek_hybrid(fast) : stk.peek();
             float4 q0, q1, q2, q3, q4, q5;
@@ -995,7 +1010,7 @@ void trace_kernel(const KParams P) {
               unsigned long long saved;
               const unsigned long long in_lds = __ballot(cur < n_cached);
               if (STATS == 2) { l_node++; if (cur < n_cached) l_cached++; if (!fast) wave_tick(lane, w_slow); }
-              const uint32_t goff = c3 << 5;
+              const uint32_t goff = off_a, goff2 = off_b;
               const uint32_t laddr = (uint32_t)(uintptr_t)(node_cache + cur);
               asm volatile(
                   "s_mov_b64 %[sv], exec\n\t"
@@ -1003,9 +1018,9 @@ void trace_kernel(const KParams P) {
                   "global_load_dwordx4 %[a0], %[go], %[nb]\n\t"
                   "global_load_dwordx4 %[a1], %[go], %[nb] offset:16\n\t"
                   "global_load_dwordx4 %[a2], %[go], %[nb] offset:32\n\t"
-                  "global_load_dwordx4 %[a3], %[go], %[nb] offset:48\n\t"
-                  "global_load_dwordx4 %[a4], %[go], %[nb] offset:64\n\t"
-                  "global_load_dwordx4 %[a5], %[go], %[nb] offset:80\n\t"
+                  "global_load_dwordx4 %[a3], %[go2], %[nb]\n\t"
+                  "global_load_dwordx4 %[a4], %[go2], %[nb] offset:16\n\t"
+                  "global_load_dwordx4 %[a5], %[go2], %[nb] offset:32\n\t"
                   "s_and_b64 exec, %[sv], %[m]\n\t"
                   "ds_read_b128 %[a0], %[la]\n\t"
                   "ds_read_b128 %[a1], %[la] offset:12288\n\t"
@@ -1017,14 +1032,14 @@ void trace_kernel(const KParams P) {
                   "s_waitcnt vmcnt(0) lgkmcnt(0)"
                   : [a0] "=&v"(w0), [a1] "=&v"(w1), [a2] "=&v"(w2), [a3] "=&v"(w3), [a4] "=&v"(w4), [a5] "=&v"(w5),
                     [sv] "=&s"(saved)
-                  : [go] "v"(goff), [la] "v"(laddr), [nb] "s"(nodes_base), [m] "s"(in_lds)
+                  : [go] "v"(goff), [go2] "v"(goff2), [la] "v"(laddr), [nb] "s"(nodes_base), [m] "s"(in_lds)
                   : "memory");
               static_assert(kWideCached * 16 == 12288, "the plane offsets in the asm above are kWideCached * 16 apart");
               q0 = make_float4(w0.x, w0.y, w0.z, w0.w); q1 = make_float4(w1.x, w1.y, w1.z, w1.w);
               q2 = make_float4(w2.x, w2.y, w2.z, w2.w); q3 = make_float4(w3.x, w3.y, w3.z, w3.w);
               q4 = make_float4(w4.x, w4.y, w4.z, w4.w); q5 = make_float4(w5.x, w5.y, w5.z, w5.w);
             } else {
-              q0 = n[0]; q1 = n[1]; q2 = n[2]; q3 = n[3]; q4 = n[4]; q5 = n[5];
+              q0 = n[0]; q1 = n[1]; q2 = n[2]; q3 = n2[0]; q4 = n2[1]; q5 = n2[2];
             }
             if (STATS) n_nodes++;
             // children 0,1 sit in q0..q2 and children 2,3 in q3..q5 exactly as the two
@@ -1055,10 +1070,10 @@ void trace_kernel(const KParams P) {
                      r2 = lowbytes(q3.x, q3.y, q3.z, q3.w), r3 = lowbytes(q4.z, q4.w, q5.x, q5.y);
             // keys: ((bits of tnear) & ~3) | child for a hit, all ones for a miss; tnear >= tmin >= 0
             const bool h0 = tn[0] <= tf[0], h1 = tn[1] <= tf[1], h2 = tn[2] <= tf[2], h3 = tn[3] <= tf[3];
-            uint32_t k0 = h0 ? ((__float_as_uint(tn[0]) & 0x7FFFFFFCu) | 0u) : 0xFFFFFFFFu;
-            uint32_t k1 = h1 ? ((__float_as_uint(tn[1]) & 0x7FFFFFFCu) | 1u) : 0xFFFFFFFFu;
-            uint32_t k2 = h2 ? ((__float_as_uint(tn[2]) & 0x7FFFFFFCu) | 2u) : 0xFFFFFFFFu;
-            uint32_t k3 = h3 ? ((__float_as_uint(tn[3]) & 0x7FFFFFFCu) | 3u) : 0xFFFFFFFFu;
+            uint32_t k0 = h0 ? ((__float_as_uint(tn[0]) & 0x7FFFFFFCu) | (0u ^ sw2)) : 0xFFFFFFFFu;
+            uint32_t k1 = h1 ? ((__float_as_uint(tn[1]) & 0x7FFFFFFCu) | (1u ^ sw2)) : 0xFFFFFFFFu;
+            uint32_t k2 = h2 ? ((__float_as_uint(tn[2]) & 0x7FFFFFFCu) | (2u ^ sw2)) : 0xFFFFFFFFu;
+            uint32_t k3 = h3 ? ((__float_as_uint(tn[3]) & 0x7FFFFFFCu) | (3u ^ sw2)) : 0xFFFFFFFFu;
             const int n_hit = (int)h0 + (int)h1 + (int)h2 + (int)h3;
             // five compare-exchanges on (key, reference) pairs: ascending keys
 #define RTGPU_CX(ka, ra, kb, rb) do { const bool sw_ = kb < ka; const uint32_t tk_ = sw_ ? kb : ka, tr_ = sw_ ? rb : ra; \
@@ -1426,6 +1441,18 @@ __global__ __launch_bounds__(256) void untile_kernel(const T *gathered, T *image
   }
 }
 
+// four-wide nodes, 96 bytes apart -> the same nodes in 128-byte slots (modes 9, 10): one thread per 16-byte piece
+__global__ __launch_bounds__(256) void pad_nodes4_kernel(const float4 *src, float4 *dst, uint64_t n_nodes) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t step = (uint64_t)gridDim.x * blockDim.x, n = n_nodes * 8;
+  for (; i < n; i += step) {
+    // node k starts 0 or 32 bytes into its slot (bit 1 of k): with the half exchange of odd nodes in the node step, the lanes
+    // of a load spread over four 16-byte positions of their lines
+    const uint64_t node = i >> 3, piece = i & 7, first = (node & 2u) ? 2u : 0u;
+    dst[i] = (piece >= first && piece < first + 6) ? src[node * 6 + (piece - first)] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
 // ---- static device scratch of rtgpu_render_device_static (the entry point that allocates
 // nothing, include/rtgpu.h) ---------------------------------------------------------------
 // One array per GPU the library runs on, held until the process ends:
@@ -1473,6 +1500,11 @@ struct rtgpu_ctx {
   void *d_nodes48 = nullptr;    // packed nodes of a tree of >= RTGPU_NODE48_MIN_NODES nodes, else NULL
   void *d_nodes4 = nullptr;     // four-wide packed nodes of such a tree, else NULL
   void *d_nodes4_src = nullptr; // their source map (4 u32 per node), read by a refit
+  // the same four-wide nodes in 128-byte slots (kernel modes 9, 10), for trees far larger than the caches: made by the first
+  // frame after an upload, build or refit (pad_valid says whether it mirrors d_nodes4)
+  void *d_nodes4_pad = nullptr; size_t nodes4_pad_bytes = 0;
+  bool pad_valid = false;
+  int pad_nodes4 = -1;          // RTGPU_NODE4_PAD=0/1 forces the choice; -1: by the size of the tree (kPadMinBytes)
   uint32_t *d_refit_ws = nullptr; // refit scratch (3 u32 per node), allocated by the first refit of a scene
   rtgpu::DevPool pool;            // device memory kept between rtgpu_build_device calls (dev_pool.h)
   bool no_wide = false;         // RTGPU_NO_WIDE=1: keep the BVH2 traversal on large trees (experiments)
@@ -1529,11 +1561,12 @@ namespace {
 // code path; the threshold only changes WHEN finished lanes are refilled, never
 // what a path computes.  RTGPU_REFILL (0/20/40) selects it for experiments.
 using KernelFn = void (*)(const KParams);
-constexpr int kModes = 9;
-struct Variant { int refill; KernelFn fn[3][kModes]; };  // [plain, stats, profile][MODE 0..8 of trace_kernel]
+constexpr int kModes = 11;
+struct Variant { int refill; KernelFn fn[3][kModes]; };  // [plain, stats, profile][MODE 0..10 of trace_kernel]
 #define RTGPU_VARIANT_ROW(S, R)                                                                         \
   {trace_kernel<S, R, 0>, trace_kernel<S, R, 1>, trace_kernel<S, R, 2>, trace_kernel<S, R, 3>, trace_kernel<S, R, 4>, \
-   trace_kernel<S, R, 5>, trace_kernel<S, R, 6>, trace_kernel<S, R, 7>, trace_kernel<S, R, 8>}
+   trace_kernel<S, R, 5>, trace_kernel<S, R, 6>, trace_kernel<S, R, 7>, trace_kernel<S, R, 8>, trace_kernel<S, R, 9>, \
+   trace_kernel<S, R, 10>}
 #define RTGPU_VARIANT(R) {R, {RTGPU_VARIANT_ROW(0, R), RTGPU_VARIANT_ROW(1, R), RTGPU_VARIANT_ROW(2, R)}}
 #ifndef RTGPU_REFILL_SMALL
 #define RTGPU_REFILL_SMALL 20
@@ -1550,7 +1583,11 @@ constexpr int kVariantSmallTree = 1, kVariantLargeTree = 2;
 #ifndef RTGPU_RAYS2_DEFAULT
 #define RTGPU_RAYS2_DEFAULT 0
 #endif
-constexpr bool kRays2Default = RTGPU_RAYS2_DEFAULT != 0;  // MODE 8 for scenes that fit LDS whole (RTGPU_RAYS2 overrides)
+constexpr bool kRays2Default = RTGPU_RAYS2_DEFAULT != 0;
+#ifndef RTGPU_PAD_MIN_MB
+#define RTGPU_PAD_MIN_MB 128
+#endif
+constexpr uint64_t kPadMinBytes = (uint64_t)RTGPU_PAD_MIN_MB << 20;  // four-wide node arrays from this size on are traversed in 128-byte slots  // MODE 8 for scenes that fit LDS whole (RTGPU_RAYS2 overrides)
 
 bool hip_fail(rtgpu_ctx *ctx, hipError_t e, const char *what) {
   if (e == hipSuccess) return false;
@@ -1570,6 +1607,7 @@ void free_scene_device(rtgpu_ctx *ctx) {
   ctx->d_refit_ws = nullptr;
   ctx->d_nodes = ctx->d_tris = ctx->d_sphs = ctx->d_sph_meta = ctx->d_mats = ctx->d_nodes48 = ctx->d_nodes4 = nullptr;
   ctx->d_nodes4_src = nullptr;
+  ctx->pad_valid = false;  // (the padded copy's memory is kept for the next scene)
   rtgpu::free_flat_scene(&ctx->host);
   ctx->have_scene = false;
   ctx->host_stale = false;
@@ -1670,6 +1708,7 @@ extern "C" int rtgpu_create(rtgpu_ctx **out, int device_index) {
   if (const char *env = std::getenv("RTGPU_NO_SPHERE_CACHE")) ctx->no_sphere_cache = std::atoi(env) != 0;
   if (const char *env = std::getenv("RTGPU_NO_TINY")) ctx->no_tiny = std::atoi(env) != 0;
   if (const char *env = std::getenv("RTGPU_RAYS2")) ctx->rays2 = std::atoi(env) != 0 ? 1 : 0;
+  if (const char *env = std::getenv("RTGPU_NODE4_PAD")) ctx->pad_nodes4 = std::atoi(env) != 0 ? 1 : 0;
   if (const char *env = std::getenv("RTGPU_NO_MATS_CACHE")) ctx->no_mats_cache = std::atoi(env) != 0;
   if (const char *env = std::getenv("RTGPU_STACK_LDS")) {
     int want = std::atoi(env);
@@ -1712,6 +1751,7 @@ extern "C" void rtgpu_destroy(rtgpu_ctx *ctx) {
   (void)hipFree(ctx->d_ovf);
   (void)hipFree(ctx->d_wave_times);
   (void)hipFree(ctx->d_planes);
+  (void)hipFree(ctx->d_nodes4_pad);
   (void)hipFree(ctx->d_accum);
   (void)hipFree(ctx->d_ids);
   (void)hipFree(ctx->d_res_accum);
@@ -1954,6 +1994,7 @@ extern "C" int rtgpu_refit(rtgpu_ctx *ctx, const rtgpu_scene_desc *scene) {
   }
   h.build_ms = ms;
   ctx->res_valid = false;  // new geometry: rtgpu_render_resolved starts its sum again (include/rtgpu.h)
+  ctx->pad_valid = false;  // ... and the padded copy of the four-wide nodes is remade by the next frame
   return 0;
 }
 
@@ -1992,6 +2033,7 @@ extern "C" int rtgpu_refit_device(rtgpu_ctx *ctx, const void *d_spheres, uint64_
   }
   h.build_ms = ms;
   ctx->res_valid = false;  // new geometry: rtgpu_render_resolved starts its sum again (include/rtgpu.h)
+  ctx->pad_valid = false;  // ... and the padded copy of the four-wide nodes is remade by the next frame
   return 0;
 }
 
@@ -2216,6 +2258,31 @@ int launch_frame(rtgpu_ctx *ctx, const rtgpu_camera *cam, const rtgpu_settings *
   if (wide || ctx->d_nodes48) {  // never a MODE 2 tree: RTGPU_NODE48_MIN_NODES > kSmallNodes
     if (mode == 2 || mode >= 7) { ctx->err = "internal: packed nodes on a tree that fits the LDS cache"; return 2; }
     mode += wide ? 5 : 3;
+  }
+  // Trees far larger than the caches: the four-wide nodes in 128-byte slots (modes 9, 10).  The padded copy is made here, by
+  // the first frame after an upload / build / refit; the entry point that may not allocate uses it only if it exists already.
+  if ((mode == 5 || mode == 6) && !wide_cache) {
+    const uint64_t n4 = ctx->host.n_nodes4, bytes96 = n4 * sizeof(rtgpu_node4), bytes128 = n4 * 128;
+    const bool want_pad = (ctx->pad_nodes4 >= 0 ? ctx->pad_nodes4 != 0 : bytes96 >= kPadMinBytes) && n4 > 0 && bytes128 < (1ull << 32);
+    if (want_pad && (sc.may_allocate || (ctx->pad_valid && ctx->nodes4_pad_bytes >= bytes128))) {
+      if (!ctx->pad_valid || ctx->nodes4_pad_bytes < bytes128) {
+        if (ctx->nodes4_pad_bytes < bytes128) {
+          HIP_TRY(ctx, hipStreamSynchronize(stream));
+          (void)hipFree(ctx->d_nodes4_pad);
+          ctx->d_nodes4_pad = nullptr;
+          ctx->nodes4_pad_bytes = 0;
+          HIP_TRY(ctx, hipMalloc(&ctx->d_nodes4_pad, bytes128));
+          ctx->nodes4_pad_bytes = bytes128;
+        }
+        const uint64_t blocks = (n4 * 8 + 255) / 256;
+        hipLaunchKernelGGL(pad_nodes4_kernel, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, stream,
+                           (const float4 *)ctx->d_nodes4, (float4 *)ctx->d_nodes4_pad, n4);
+        HIP_TRY(ctx, hipGetLastError());
+        ctx->pad_valid = true;
+      }
+      P.nodes = (const float4 *)ctx->d_nodes4_pad;
+      mode += 4;  // 5 -> 9, 6 -> 10
+    }
   }
   if (wide_cache) {  // mode == 5
     P.n_cached = (uint32_t)(ctx->host.n_nodes4 < (uint64_t)kWideCached ? ctx->host.n_nodes4 : (uint64_t)kWideCached);

@@ -15,6 +15,8 @@ CASES = [
     ({"RTGPU_NO_SPHERE_CACHE": "1"}, (2, 6)),                       # the tree in LDS, spheres through L1
     ({"RTGPU_RAYS2": "1"}, (8, 6)),                                 # two rays per lane in lock step (scenes in LDS)
     ({"RTGPU_RAYS2": "0"}, (7, 6)),                                 # one ray per lane
+    ({"RTGPU_NODE4_PAD": "1"}, (7, 10)),                            # four-wide nodes in 128-byte slots (what huge trees run on)
+    ({"RTGPU_NODE4_PAD": "1", "RTGPU_STACK_LDS": "14"}, (7, 9)),    # ... with the deeper stack entries in memory
     ({"RTGPU_WIDE_CACHE": "1"}, (7, 5)),                            # experiment A: top of the four-wide tree in LDS
     ({"RTGPU_REFILL": "0"}, (7, 6)),                                # plain while-while traversal rounds
     ({"RTGPU_NO_MATS_CACHE": "1"}, (7, 6)),                         # trees in memory: materials through L1, not LDS
