@@ -81,6 +81,39 @@ typedef struct rtgpu_node4 {
  * later node. */
 #define RTGPU_TOP_NODES4 1024u
 
+/* Slot tree: the four-wide tree AND its primitives as one array of 64-byte slots (16 words), made on the
+ * device from the four-wide nodes and the leaf-ordered arrays (rt_amd/csrc/slot_tree.hip; restated in
+ * oracle/rt_oracle.c) and traversed in preference to them by the trace loop and the oracle.  On trees in
+ * memory the trace loop's time follows the 16-byte loads a lane issues and the 128-byte lines they touch
+ * (DESIGN.md §5.2): a node is four loads here instead of six, no record lies across a line, and the
+ * children of a node are adjacent.
+ *   node slot      w0 w1 w2  origin x y z (f32): per axis the smallest lo plane of the node's children, moved
+ *                            DOWN to the nearest float whose LOW BYTE is the child byte of child 0 / 1 / 2;
+ *                            the float AS STORED is the origin, nothing is masked
+ *                  w3        bits 0..23 FAMILY = slot of the node's first child; bits 24..31 child byte of child 3
+ *                  w[4+3k+a] child k (0..3), axis a (x y z): low half = binary16 of (lo - origin) rounded DOWN,
+ *                            high half = binary16 of (hi - origin) rounded UP (differences taken in double;
+ *                            zero and NORMAL halves only: a positive difference below 2^-14 becomes 0 / 2^-14);
+ *                            a missing child has +inf (0x7C00) in all six halves, which no ray reaches
+ *   child byte     bits 0..3 = the top four bits of the child's slot reference (leaf, sphere, count - 1);
+ *                  bits 4..7 = where the child starts in the family, in slots
+ *   family         the children of one node in child order: an inner child is 1 slot (its node), a leaf of n
+ *                  primitives n slots.  Slot 0 is the root; the family of four-wide node i starts at
+ *                  1 + (slots of the families of nodes 0 .. i-1), so every child lies after its parent
+ *   triangle slot  words 0..11 = rtgpu_tri, 12..15 zero
+ *   sphere slot    words 0..3 = rtgpu_sph, 4 = prim_id, 5 = material, 6..15 zero
+ * Slot reference (the traversal-stack entry over this tree): bit 31 leaf, bit 30 sphere, bits 28..29
+ * count - 1, bits 0..27 the first slot; inner node: its slot.  The slab test of child k, axis a is
+ *   t = fmaf(half, 1/d, adj),  adj = fmaf(origin, 1/d, -o/d)   (adj once per node and axis)
+ * with the half converted exactly (v_fma_mix_f32 on gfx950); traversal order as over rtgpu_node4.
+ * The boxes contain the four-wide nodes' boxes (planes move outward by less than 2^-10 of their distance
+ * from the origin), so the hits are the same and only the visit counts grow (by ~0.2 %).
+ * A tree has NO slot form - and is traversed through rtgpu_node4 - if a leaf holds more than four
+ * primitives, a plane lies more than 65504 above its node's origin, or it would take 2^24 slots (1 GiB)
+ * or more. */
+#define RTGPU_SLOT_WORDS 16u
+#define RTGPU_SLOT_MAX   (1u << 24)
+
 /* Child reference (also the traversal-stack entry):
  *   bit 31 = 0 : inner node, bits 0..30 = node index
  *   bit 31 = 1 : leaf; bit 30 = 1 sphere / 0 triangle;

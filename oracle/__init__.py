@@ -55,6 +55,13 @@ def load():
     lib.rto_render.argtypes = [
         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
         C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int]
+    lib.rto_render_slots.argtypes = lib.rto_render.argtypes + [C.c_void_p]
+    lib.rto_set_slot_tree.argtypes = [C.c_int]
+    lib.rto_set_slot_tree.restype = None
+    lib.rto_build_slot_tree.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    lib.rto_build_slot_tree.restype = C.c_void_p
+    lib.rto_free_words.argtypes = [C.c_void_p]
+    lib.rto_free_words.restype = None
     lib.rto_resolve_rgba8.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     lib.rto_resolve_rgba8.restype = None
     lib.rto_validate_bvh.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
@@ -99,20 +106,43 @@ class Oracle:
     def __init__(self):
         self.lib = load()
 
+    def slot_tree(self, flat_c):
+        """The slot tree (include/rtgpu_format.h) of a flattened scene with four-wide nodes: u32 array
+        [n_slots, 16], or None if the tree has no slot form (then the four-wide nodes are traversed)."""
+        n = C.c_uint64()
+        p = self.lib.rto_build_slot_tree(C.addressof(flat_c), C.byref(n))
+        if not p:
+            if n.value:
+                raise MemoryError("rto_build_slot_tree")
+            return None
+        try:
+            return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint32)), shape=(n.value, 16)).copy()
+        finally:
+            self.lib.rto_free_words(p)
+
     def render(self, flat_c, cam, settings, accum=None, crop=None, brute_force=False, threads=1,
-               want_ids=True):
+               want_ids=True, slot_tree=True, slots=None):
         """flat_c: rtgpu_flat_scene ctypes struct; cam/settings: ctypes structs of
-        rt_amd.api (plain data).  Returns (accum[h,w,4], prim_id[h,w], stats dict)."""
+        rt_amd.api (plain data).  Returns (accum[h,w,4], prim_id[h,w], stats dict).
+        slot_tree: traverse the slot tree of a scene with four-wide nodes when it has one (what the
+        product does by default; False = the four-wide nodes, RTGPU_SLOT_TREE=0 there).  slots: a tree
+        from slot_tree() to traverse, instead of building it for this call."""
         w, h = settings.width, settings.height
         if accum is None:
             accum = np.zeros((h, w, 4), np.float32)
         ids = np.full((h, w), 0xFFFFFFFF, np.uint32) if want_ids else None
         stats = (C.c_uint64 * 6)()
         x0, y0, x1, y1 = crop if crop is not None else (0, 0, w, h)
-        rc = self.lib.rto_render(
-            C.addressof(flat_c), C.addressof(cam), C.addressof(settings), accum.ctypes.data,
-            ids.ctypes.data if ids is not None else None, C.addressof(stats), x0, y0, x1, y1,
-            1 if brute_force else 0, threads)
+        args = (C.addressof(flat_c), C.addressof(cam), C.addressof(settings), accum.ctypes.data,
+                ids.ctypes.data if ids is not None else None, C.addressof(stats), x0, y0, x1, y1,
+                1 if brute_force else 0, threads)
+        if slots is not None:
+            assert slots.dtype == np.uint32 and slots.flags.c_contiguous
+            rc = self.lib.rto_render_slots(*args, slots.ctypes.data)
+        else:
+            self.lib.rto_set_slot_tree(1 if slot_tree else 0)
+            rc = self.lib.rto_render(*args)
+            self.lib.rto_set_slot_tree(1)
         if rc:
             raise RuntimeError(f"rto_render failed with {rc}")
         keys = ("paths", "rays", "nodes", "tri_tests", "sphere_tests", "scatters")

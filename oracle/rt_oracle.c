@@ -226,6 +226,7 @@ typedef struct {
   const rtgpu_node *nodes;
   const rtgpu_node48 *nodes48; /* packed form (rtgpu_format.h); traversed instead of nodes when present */
   const rtgpu_node4 *nodes4;   /* four-wide packed form; traversed in preference when present */
+  const uint32_t *slots;       /* slot tree (rtgpu_format.h), 16 words per slot; traversed in preference when present */
   const rtgpu_tri *tris;
   const rtgpu_sph *sphs;
   const uint32_t *sph_meta;
@@ -238,7 +239,7 @@ typedef struct {
 typedef struct {
   int hit;
   int is_sphere;
-  uint32_t slot;  /* index into the leaf-ordered array of its type */
+  uint32_t slot;  /* index into the leaf-ordered array of its type (slot tree: the primitive's slot) */
   float t;
 } hit_t;
 
@@ -330,7 +331,93 @@ static hit_t intersect_bvh4(const scene_t *sc, const ray_t *r, float tmin, count
   return best;
 }
 
+/* binary16 (zero, normal, +inf: all the slot tree holds) -> float, exactly */
+static inline float half_to_float(uint32_t h) {
+  uint32_t e = (h >> 10) & 0x1Fu, m = h & 0x3FFu, bits;
+  if (e == 0) bits = 0u;                       /* zero (the builder writes no subnormal) */
+  else if (e == 31) bits = 0x7F800000u;        /* +inf: a missing child */
+  else bits = ((e + 112u) << 23) | (m << 13);  /* rebias 15 -> 127 */
+  float f;
+  memcpy(&f, &bits, 4);
+  return f;
+}
+
+/* Closest hit over the slot tree (include/rtgpu_format.h): the traversal of intersect_bvh4 - up to four
+ * children per node, visited by ascending key ((bits of tnear) & 0x7FFFFFFC) | k - over node slots whose
+ * child boxes are binary16 offsets from the node's origin: per axis a = fmaf(origin, 1/d, -o/d) once, then
+ * every plane t = fmaf(half, 1/d, a) (on gfx950 one v_fma_mix_f32 each).  The origin words are the floats AS
+ * STORED (their low bytes carry the child bytes).  Slot references: bit 31 leaf, bit 30 sphere, bits 28..29
+ * count - 1, bits 0..27 the first slot; a leaf's primitives sit in consecutive slots. */
+static hit_t intersect_slots(const scene_t *sc, const ray_t *r, float tmin, counters_t *cn) {
+  hit_t best = {0, 0, 0, T_MAX};
+  uint32_t stack[3 * (RTGPU_MAX_TREE_DEPTH + 2) + 2];
+  int sp = 0;
+  uint32_t cur = 0; /* root */
+  for (;;) {
+    if (cur & RTGPU_REF_LEAF) {
+      uint32_t first = cur & 0x0FFFFFFFu, count = ((cur >> 28) & 3u) + 1u;
+      for (uint32_t i = first; i < first + count; i++) {
+        float t;
+        if (cur & RTGPU_REF_SPHERE) {
+          cn->sphere_tests++;
+          if (hit_sphere(r, (const rtgpu_sph *)(sc->slots + 16 * (size_t)i), tmin, best.t, &t)) {
+            best.hit = 1; best.is_sphere = 1; best.slot = i; best.t = t;
+          }
+        } else {
+          cn->tri_tests++;
+          if (hit_tri(r, (const rtgpu_tri *)(sc->slots + 16 * (size_t)i), tmin, best.t, &t)) {
+            best.hit = 1; best.is_sphere = 0; best.slot = i; best.t = t;
+          }
+        }
+      }
+    } else {
+      const uint32_t *w = sc->slots + 16 * (size_t)cur;
+      float org[3];
+      memcpy(org, w, sizeof(org));
+      cn->nodes++;
+      const float ax = fmaf(org[0], r->inv.x, r->noi.x), ay = fmaf(org[1], r->inv.y, r->noi.y),
+                  az = fmaf(org[2], r->inv.z, r->noi.z);
+      const uint32_t family = w[3] & 0x00FFFFFFu;
+      const uint32_t byte[4] = {w[0] & 0xFFu, w[1] & 0xFFu, w[2] & 0xFFu, w[3] >> 24};
+      uint32_t key[4], ref[4];
+      int n = 0;
+      for (int k = 0; k < 4; k++) {
+        const uint32_t *cw = w + 4 + 3 * k;
+        float t0x = fmaf(half_to_float(cw[0] & 0xFFFFu), r->inv.x, ax), t1x = fmaf(half_to_float(cw[0] >> 16), r->inv.x, ax);
+        float t0y = fmaf(half_to_float(cw[1] & 0xFFFFu), r->inv.y, ay), t1y = fmaf(half_to_float(cw[1] >> 16), r->inv.y, ay);
+        float t0z = fmaf(half_to_float(cw[2] & 0xFFFFu), r->inv.z, az), t1z = fmaf(half_to_float(cw[2] >> 16), r->inv.z, az);
+        float tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), tmin));
+        float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), best.t));
+        int h = tn <= tf;
+        uint32_t tb;
+        memcpy(&tb, &tn, 4);
+        /* child byte: low nibble = top four bits of the reference, high nibble = place in the family */
+        ref[k] = ((byte[k] & 0xFu) << 28) | (family + (byte[k] >> 4));
+        key[k] = h ? ((tb & 0x7FFFFFFCu) | (uint32_t)k) : 0xFFFFFFFFu;
+        n += h;
+      }
+      if (n > 0) {
+        uint32_t ord[4] = {key[0], key[1], key[2], key[3]};
+        for (int a = 1; a < 4; a++) {
+          uint32_t v = ord[a];
+          int b = a - 1;
+          while (b >= 0 && ord[b] > v) { ord[b + 1] = ord[b]; b--; }
+          ord[b + 1] = v;
+        }
+        for (int a = n - 1; a >= 1; a--) stack[sp++] = ref[ord[a] & 3u];
+        if (sp > g_max_stack) g_max_stack = sp;
+        cur = ref[ord[0] & 3u];
+        continue;
+      }
+    }
+    if (sp == 0) break;
+    cur = stack[--sp];
+  }
+  return best;
+}
+
 static hit_t intersect_bvh(const scene_t *sc, const ray_t *r, float tmin, counters_t *cn) {
+  if (sc->slots) return intersect_slots(sc, r, tmin, cn);
   if (sc->nodes4) return intersect_bvh4(sc, r, tmin, cn);
   hit_t best = {0, 0, 0, T_MAX};
   uint32_t stack[RTGPU_MAX_TREE_DEPTH + 2];
@@ -581,7 +668,15 @@ static v3 trace_path(const job_t *J, uint32_t x, uint32_t y, uint32_t sample, ui
     v3 p = v3_add(r.o, v3_scale(r.d, h.t));
     v3 n;
     uint32_t prim, mat;
-    if (h.is_sphere) {
+    if (h.is_sphere && J->sc->slots && !J->brute) { /* sphere slot: {c, r}, then {prim_id, material} */
+      const uint32_t *w = J->sc->slots + 16 * (size_t)h.slot;
+      const rtgpu_sph *s = (const rtgpu_sph *)w;
+      v3 c = {s->c[0], s->c[1], s->c[2]};
+      float inv_r = 1.0f / s->r;
+      n = v3_scale(v3_sub(p, c), inv_r);
+      prim = w[4];
+      mat = w[5];
+    } else if (h.is_sphere) {
       const rtgpu_sph *s = &J->sc->sphs[h.slot];
       v3 c = {s->c[0], s->c[1], s->c[2]};
       float inv_r = 1.0f / s->r;
@@ -589,7 +684,8 @@ static v3 trace_path(const job_t *J, uint32_t x, uint32_t y, uint32_t sample, ui
       prim = J->sc->sph_meta[2 * h.slot];
       mat = J->sc->sph_meta[2 * h.slot + 1];
     } else {
-      const rtgpu_tri *tr = &J->sc->tris[h.slot];
+      const rtgpu_tri *tr = (J->sc->slots && !J->brute) ? (const rtgpu_tri *)(J->sc->slots + 16 * (size_t)h.slot)
+                                                        : &J->sc->tris[h.slot];
       n = v3_normalize(v3_cross(v3_from(tr->e1), v3_from(tr->e2)));
       prim = tr->prim_id;
       mat = tr->material;
@@ -623,10 +719,18 @@ static v3 trace_path(const job_t *J, uint32_t x, uint32_t y, uint32_t sample, ui
  * consecutive samples (rtgpu_settings.chunk_samples), then
  *   out = (ACCUMULATE ? in : 0) + (sum.r, sum.g, sum.b, (f32)spp).
  */
-RTO_API int rto_render(const rtgpu_flat_scene *fs, const rtgpu_camera *cam, const rtgpu_settings *st,
-                       float *accum, uint32_t *prim_id, rtgpu_stats *stats, uint32_t x0, uint32_t y0,
-                       uint32_t x1, uint32_t y1, int brute_force, int nthreads) {
+RTO_API uint32_t *rto_build_slot_tree(const rtgpu_flat_scene *fs, uint64_t *n_slots);
+/* What rto_render traverses when the scene has four-wide nodes: their slot tree if the tree has one (1, the
+ * default: what the product's trace loop does) or the four-wide nodes themselves (0: RTGPU_SLOT_TREE=0 there). */
+static int g_slot_tree = 1;
+RTO_API void rto_set_slot_tree(int on) { g_slot_tree = on; }
+
+/* slots: the scene's slot tree from rto_build_slot_tree (traversed), or NULL (the four-wide / packed / plain nodes) */
+RTO_API int rto_render_slots(const rtgpu_flat_scene *fs, const rtgpu_camera *cam, const rtgpu_settings *st,
+                             float *accum, uint32_t *prim_id, rtgpu_stats *stats, uint32_t x0, uint32_t y0,
+                             uint32_t x1, uint32_t y1, int brute_force, int nthreads, const uint32_t *slots) {
   scene_t sc;
+  sc.slots = slots;
   sc.nodes = (const rtgpu_node *)fs->nodes;
   sc.nodes48 = (const rtgpu_node48 *)fs->nodes48;
   sc.nodes4 = (const rtgpu_node4 *)fs->nodes4;
@@ -705,6 +809,20 @@ RTO_API int rto_render(const rtgpu_flat_scene *fs, const rtgpu_camera *cam, cons
     stats->scatters = total.scatters;
   }
   return 0;
+}
+
+RTO_API int rto_render(const rtgpu_flat_scene *fs, const rtgpu_camera *cam, const rtgpu_settings *st,
+                       float *accum, uint32_t *prim_id, rtgpu_stats *stats, uint32_t x0, uint32_t y0,
+                       uint32_t x1, uint32_t y1, int brute_force, int nthreads) {
+  uint32_t *slots = NULL;
+  if (g_slot_tree && fs->nodes4 && !brute_force) {
+    uint64_t n_slots = 0;
+    slots = rto_build_slot_tree(fs, &n_slots);
+    if (!slots && n_slots) return 2; /* out of memory */
+  }
+  int rc = rto_render_slots(fs, cam, st, accum, prim_id, stats, x0, y0, x1, y1, brute_force, nthreads, slots);
+  free(slots);
+  return rc;
 }
 
 /* Resolve (row a8): mean, gamma 2, clamp, 8 bits per channel, 0xRRGGBBAA
@@ -971,6 +1089,142 @@ RTO_API int rto_pack_node48(const rtgpu_node *n, rtgpu_node48 *out) {
   memcpy(out->w, w, sizeof(w));
   return 1;
 }
+
+/* ==== Slot tree (include/rtgpu_format.h) ============================================
+ *
+ * CPU restatement of rt_amd/csrc/slot_tree.hip (no reference counterpart: the reference has no BVH,
+ * SURVEY.md §0): the four-wide nodes and the primitives they name as ONE array of 64-byte slots.
+ *  - family of node i (its children, in child order: an inner child 1 slot, a leaf of n primitives n
+ *    slots) starts at slot 1 + (slots of the families of nodes 0 .. i-1); the root is slot 0;
+ *  - node slot: words 0..2 the origin (per axis the smallest lo plane of the children that exist,
+ *    moved DOWN to the nearest float whose low byte is the child byte of child 0 / 1 / 2), word 3 =
+ *    family | child byte of child 3 << 24, words 4 + 3k + a = half(lo - origin) | half(hi - origin) << 16
+ *    for child k, axis a: the differences in double, rounded DOWN / UP to zero or a normal binary16
+ *    (0x7C00 twice for a missing child);
+ *  - child byte = place in the family << 4 | leaf << 3 | sphere << 2 | count - 1;
+ *  - triangle slot: the 48 bytes of rtgpu_tri, sphere slot: rtgpu_sph then {prim_id, material}; zero after.
+ * A tree with a leaf of more than four primitives, a child box more than 65504 from the origin or 2^24
+ * slots or more has no slot form (the four-wide nodes are traversed).  The half rounding here works on
+ * frexp / ldexp / floor / ceil, the product's on the bits of the double, so that the two check each other. */
+static int half_round(double d, int up, uint32_t *out) {
+  if (!(d >= 0.0)) return 0;
+  if (d < 0x1p-14) { *out = (up && d > 0.0) ? 0x0400u : 0u; return 1; }
+  if (d >= 65536.0) { if (up) return 0; *out = 0x7BFFu; return 1; }
+  int ex;
+  (void)frexp(d, &ex); /* d = m * 2^ex, m in [0.5, 1) */
+  int e = ex - 1;
+  double q = ldexp(d, 10 - e); /* in [1024, 2048), exact */
+  double qi = up ? ceil(q) : floor(q);
+  if (qi >= 2048.0) { e++; qi = 1024.0; }
+  if (e > 15) { if (up) return 0; *out = 0x7BFFu; return 1; }
+  *out = ((uint32_t)(e + 15) << 10) | ((uint32_t)qi - 1024u);
+  return 1;
+}
+
+typedef struct { uint32_t ref, size, nibble; } slot_child_t;
+static int slot_child_of(const rtgpu_node4 *n, int k, slot_child_t *c) {
+  const uint32_t *cw = n->w + 6 * k;
+  c->ref = (cw[0] & 0xFFu) | ((cw[1] & 0xFFu) << 8) | ((cw[2] & 0xFFu) << 16) | ((cw[3] & 0xFFu) << 24);
+  c->size = 0; c->nibble = 0;
+  if (c->ref == RTGPU_REF_EMPTY) return 1;
+  if (!(c->ref & RTGPU_REF_LEAF)) { c->size = 1; return 1; }
+  uint32_t count = RTGPU_REF_COUNT(c->ref);
+  if (count > 4u) return 0;
+  c->size = count;
+  c->nibble = 8u | ((c->ref & RTGPU_REF_SPHERE) ? 4u : 0u) | (count - 1u);
+  return 1;
+}
+
+/* The slot tree of a flattened scene that has four-wide nodes: malloc'ed, 16 words per slot, *n_slots of
+ * them; NULL with *n_slots = 0 if the tree has no slot form (or no four-wide nodes), NULL with *n_slots = 1
+ * if memory ran out. */
+RTO_API uint32_t *rto_build_slot_tree(const rtgpu_flat_scene *fs, uint64_t *n_slots) {
+  *n_slots = 0;
+  const rtgpu_node4 *n4 = (const rtgpu_node4 *)fs->nodes4;
+  const uint64_t n = fs->n_nodes4;
+  if (!n4 || n == 0 || n >= (1ull << 24)) return NULL;
+  uint32_t *family = malloc((size_t)n * sizeof(uint32_t)), *slot_of = malloc((size_t)n * sizeof(uint32_t));
+  if (!family || !slot_of) { free(family); free(slot_of); *n_slots = 1; return NULL; }
+  uint64_t total = 1;
+  int ok = 1;
+  for (uint64_t i = 0; i < n && ok; i++) {
+    family[i] = (uint32_t)total;
+    for (int k = 0; k < 4; k++) {
+      slot_child_t c;
+      if (!slot_child_of(&n4[i], k, &c)) ok = 0;
+      total += c.size;
+    }
+    if (total >= (1ull << 24)) ok = 0;
+  }
+  uint32_t *slots = ok ? calloc((size_t)total * 16, sizeof(uint32_t)) : NULL;
+  if (ok && !slots) { free(family); free(slot_of); *n_slots = 1; return NULL; }
+  slot_of[0] = 0;
+  for (uint64_t i = 0; i < n && ok; i++) {
+    slot_child_t c[4];
+    uint32_t off[4], at = 0;
+    for (int k = 0; k < 4; k++) {
+      (void)slot_child_of(&n4[i], k, &c[k]);
+      off[k] = at;
+      at += c[k].size;
+      if (c[k].size && !(c[k].ref & RTGPU_REF_LEAF)) {
+        if (c[k].ref <= i || c[k].ref >= n) { ok = 0; break; }
+        slot_of[c[k].ref] = family[i] + off[k];
+      }
+    }
+    if (!ok) break;
+    uint32_t *w = slots + 16 * (size_t)slot_of[i];
+    float org[3];
+    for (int a = 0; a < 3 && ok; a++) {
+      int any = 0;
+      float lo = 0.0f;
+      for (int k = 0; k < 4; k++) {
+        if (c[k].ref == RTGPU_REF_EMPTY) continue;
+        float v;
+        memcpy(&v, &n4[i].w[6 * k + a], 4);
+        if (!any || v < lo) lo = v;
+        any = 1;
+      }
+      uint32_t bits;
+      memcpy(&bits, &lo, 4);
+      if (!any || !pack_plane(bits, (off[a] << 4) | c[a].nibble, 1, &w[a])) { ok = 0; break; }
+      memcpy(&org[a], &w[a], 4);
+    }
+    if (!ok) break;
+    w[3] = family[i] | (((off[3] << 4) | c[3].nibble) << 24);
+    for (int k = 0; k < 4 && ok; k++)
+      for (int a = 0; a < 3; a++) {
+        uint32_t word = 0x7C007C00u;
+        if (c[k].ref != RTGPU_REF_EMPTY) {
+          float lo, hi;
+          uint32_t hl, hh;
+          memcpy(&lo, &n4[i].w[6 * k + a], 4);
+          memcpy(&hi, &n4[i].w[6 * k + 3 + a], 4);
+          if (!half_round((double)lo - (double)org[a], 0, &hl) || !half_round((double)hi - (double)org[a], 1, &hh)) { ok = 0; break; }
+          word = hl | (hh << 16);
+        }
+        w[4 + 3 * k + a] = word;
+      }
+    for (int k = 0; k < 4 && ok; k++) {
+      if (!c[k].size || !(c[k].ref & RTGPU_REF_LEAF)) continue;
+      const uint32_t first = RTGPU_REF_FIRST(c[k].ref);
+      for (uint32_t j = 0; j < c[k].size; j++) {
+        uint32_t *p = slots + 16 * (size_t)(family[i] + off[k] + j);
+        if (c[k].ref & RTGPU_REF_SPHERE) {
+          memcpy(p, (const rtgpu_sph *)fs->spheres + (first + j), sizeof(rtgpu_sph));
+          p[4] = fs->sphere_meta[2 * (size_t)(first + j)];
+          p[5] = fs->sphere_meta[2 * (size_t)(first + j) + 1];
+        } else {
+          memcpy(p, (const rtgpu_tri *)fs->tris + (first + j), sizeof(rtgpu_tri));
+        }
+      }
+    }
+  }
+  free(family); free(slot_of);
+  if (!ok) { free(slots); return NULL; }
+  *n_slots = total;
+  return slots;
+}
+RTO_API void rto_free_words(uint32_t *p) { free(p); }
 
 /* nodes48 of a flattened scene, as the flattener adds it: NULL below the threshold */
 static rtgpu_node48 *pack_all(const rtgpu_node *nodes, uint64_t n, int *fail) {

@@ -511,6 +511,19 @@ class Context:
         """Instantiation of the last trace-kernel launch, e.g. 'trace_kernel<0,16,2>'."""
         return (lib.rtgpu_last_kernel_name(self._h) or b"").decode()
 
+    def debug_slot_tree(self):
+        """The slot tree (include/rtgpu_format.h) of the uploaded scene as the trace loop traverses it:
+        u32 array [n_slots, 16], or None if the scene has none.  Diagnostics, not part of the C ABI."""
+        fn = lib.rtgpu_debug_slot_tree
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+        n = C.c_uint64()
+        self._check(fn(self._h, None, 0, C.byref(n)))
+        if not n.value:
+            return None
+        out = np.zeros((n.value, 16), np.uint32)
+        self._check(fn(self._h, out.ctypes.data, n.value, C.byref(n)))
+        return out
+
     def resolve(self, accum):
         accum = np.ascontiguousarray(accum, np.float32)
         n = accum.size // 4

@@ -38,6 +38,16 @@ int  refresh_nodes4_device(const void *d_nodes, void *d_nodes4, const void *d_sr
 // pack48.hip: pack_nodes48 on the device (d_flag: one u32 of device scratch, or NULL to allocate it there)
 int  pack_nodes48_device(const void *d_nodes, uint64_t n, void *d_nodes48, uint32_t *d_flag, std::string &err);
 
+// slot_tree.hip: the slot tree (rtgpu_format.h) of four-wide nodes + leaf-ordered primitives, on the device.
+// d_slots is kept between calls (grow-only, the owner frees it); n_slots == 0: this tree has no slot form.
+struct SlotTreeDevice {
+  void *d_slots = nullptr;
+  size_t cap_bytes = 0;
+  uint64_t n_slots = 0;
+};
+int  build_slot_tree_device(const void *d_nodes4, uint64_t n4, const void *d_tris, const void *d_sphs, const void *d_sph_meta,
+                            SlotTreeDevice *out, DevPool *pool, void *stream /* hipStream_t */, std::string &err);
+
 // lbvh_build.hip: the same flattened scene built on the GPU (device arrays, caller frees with free_lbvh)
 struct LbvhDevice {
   void *d_nodes, *d_tris, *d_sphs, *d_sph_meta;

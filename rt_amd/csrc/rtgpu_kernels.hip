@@ -414,6 +414,9 @@ __device__ __forceinline__ void wave_tick(unsigned lane, unsigned long long &c) 
 // caches (S2 level 8: 0.4 GB of nodes, L2 hit rate 0.57, the fabric at 5.2 TB/s) the lines are what the launch waits for;
 // for trees that live in L1 / L2 the aligned slots cost more than they save (every lane of a load reads the same 16 bytes of
 // its line: bank conflicts), so the host chooses by the size of the tree.
+// 11 and 12: as 5 and 6 over the SLOT TREE (rtgpu_format.h): four-wide nodes of 64 bytes - the child boxes as binary16 offsets
+// from the node's origin, which v_fma_mix_f32 multiplies into the slab test as they are - in ONE array of 64-byte slots with
+// the primitives, the children of a node adjacent.  Four loads per node step instead of six, no record across a line.
 // (The slot-exchange experiment of round 2 - modes 8-10 then, profiles/r02/experiments.txt H and J -
 // was a measured negative and is gone from the source.)
 template <int STATS, int REFILL, int MODE>
@@ -421,10 +424,14 @@ __global__ __launch_bounds__(MODE == 8 ? kBlock2 : kBlock)
 __attribute__((amdgpu_waves_per_eu(MODE == 8 ? kBlock2 * RTGPU_BLOCKS_PER_CU / 256 : RTGPU_WAVES_PER_EU,
                                    MODE == 8 ? kBlock2 * RTGPU_BLOCKS_PER_CU / 256 : RTGPU_WAVES_PER_EU)))
 void trace_kernel(const KParams P) {
-  constexpr bool LDS_ONLY = MODE == 1 || MODE == 2 || MODE == 4 || MODE == 6 || MODE == 7 || MODE == 8 || MODE == 10, SMALL = MODE == 2 || MODE == 7 || MODE == 8,
+  constexpr bool LDS_ONLY = MODE == 1 || MODE == 2 || MODE == 4 || MODE == 6 || MODE == 7 || MODE == 8 || MODE == 10 || MODE == 12,
+                 SMALL = MODE == 2 || MODE == 7 || MODE == 8,
                  TINY = MODE == 7 || MODE == 8, PACKED = MODE == 3 || MODE == 4,
-                 WIDE = MODE == 5 || MODE == 6 || MODE == 9 || MODE == 10, HYBRID = MODE == 5 || MODE == 9,
-                 SLOT128 = MODE == 9 || MODE == 10;
+                 WIDE = MODE == 5 || MODE == 6 || MODE == 9 || MODE == 10, HYBRID = MODE == 5 || MODE == 9 || MODE == 11,
+                 SLOT128 = MODE == 9 || MODE == 10, SLOTS = MODE == 11 || MODE == 12;
+  // leaf references: bit 31 leaf, bit 30 sphere, then count - 1 and the first primitive (rtgpu_format.h); the slot tree keeps
+  // two bits of count and 28 of slot
+  constexpr uint32_t CNT_SHIFT = SLOTS ? 28u : 27u, CNT_MASK = SLOTS ? 3u : 7u, FIRST_MASK = (1u << CNT_SHIFT) - 1u;
   constexpr int R = MODE == 8 ? 2 : 1;                  // rays a lane traverses in lock step
   constexpr int BLOCK = MODE == 8 ? kBlock2 : kBlock;   // threads per block
   constexpr int STRIDE = BLOCK * R;                     // words between consecutive entries of one stack
@@ -629,7 +636,7 @@ void trace_kernel(const KParams P) {
       if (STATS == 2) { wave_tick(lane, w_shade); l_shade++; }
       V3 L = mk(0.f, 0.f, 0.f);
       bool path_end = false;
-      const uint32_t hit_slot = RTGPU_REF_FIRST(S.hit_ref);
+      const uint32_t hit_slot = S.hit_ref & FIRST_MASK;
       if (S.hit_ref == kDone) {
         float t = 0.5f * (S.rd.y + 1.0f);
         float a = 1.0f - t;
@@ -650,6 +657,7 @@ void trace_kernel(const KParams P) {
         if (S.hit_ref & RTGPU_REF_SPHERE) {
           float4 s;
           if (sph_in_lds) { const f4 w = sph_cache[hit_slot]; s = make_float4(w.x, w.y, w.z, w.w); }
+          else if (SLOTS) s = *(const float4 *)(nodes_base + (hit_slot << 6));
           else s = P.sphs[hit_slot];
           if (TINY) {
             const u2 w = meta_cache[hit_slot];
@@ -658,7 +666,7 @@ void trace_kernel(const KParams P) {
             prim = w.x;
             m0 = make_float4(a.x, a.y, a.z, a.w); m1 = make_float4(b.x, b.y, b.z, b.w);
           } else {
-            const uint2 meta = P.sph_meta[hit_slot];
+            const uint2 meta = SLOTS ? *(const uint2 *)(nodes_base + (hit_slot << 6) + 16u) : P.sph_meta[hit_slot];
             float inv_r = rcp_exact(s.w);
             n = (p - mk(s.x, s.y, s.z)) * inv_r;
             prim = meta.x;
@@ -673,7 +681,7 @@ void trace_kernel(const KParams P) {
             prim = __float_as_uint(w.w);
             m0 = make_float4(d.x, d.y, d.z, d.w); m1 = make_float4(e.x, e.y, e.z, e.w);
           } else if (!KEEP_N) {
-            const float4 *tp = P.tris + (size_t)hit_slot * (sizeof(rtgpu_tri) / 16);
+            const float4 *tp = SLOTS ? (const float4 *)(nodes_base + (hit_slot << 6)) : P.tris + (size_t)hit_slot * (sizeof(rtgpu_tri) / 16);
             const float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
             load_mat(S.hit_mat, m0, m1);
             n = normalize(cross(mk(t1.x, t1.y, t1.z), mk(t2.x, t2.y, t2.z)));
@@ -1086,7 +1094,59 @@ void trace_kernel(const KParams P) {
 #undef RTGPU_CX
             cur = HYBRID ? stk.step4_hybrid(fast, n_hit, r0, r1, r2, r3, top) : stk.step4(n_hit, r0, r1, r2, r3, top);
           }
-          if (!WIDE) {
+          if (SLOTS && (int)ray0.cur >= 0) {
+            Ray &S = ray0;
+            uint32_t &cur = S.cur;
+            StackT &stk = S.stk;
+            if (STATS == 2) wave_tick(lane, w_node);
+            // node slot at cur << 6: origin | family, then four children x three axes of (lo | hi) halves
+            const uint4 *n = (const uint4 *)(nodes_base + (cur << 6));
+            bool fast = true;
+            const uint32_t top = HYBRID ? stk.peek_hybrid(fast) : stk.peek();
+            const uint4 hd = n[0], pa = n[1], pb = n[2], pc = n[3];
+            if (STATS == 2) { l_node++; if (!fast) wave_tick(lane, w_slow); }
+            if (STATS) n_nodes++;
+            // t = half * (1/d) + (origin * (1/d) - o/d): the second term once per node and axis
+            const f2 adj_xy = __builtin_elementwise_fma(mk2(__uint_as_float(hd.x), __uint_as_float(hd.y)), S.inv_xy, S.noi_xy);
+            const float adj_z = __builtin_fmaf(__uint_as_float(hd.z), S.inv_zx.x, S.noi_zx.x);
+            const float ix = S.inv_xy.x, iy = S.inv_xy.y, iz = S.inv_zx.x, ax = adj_xy.x, ay = adj_xy.y, az = adj_z;
+            const float tbest = S.tbest;
+            auto lo_of = [](uint32_t w) { union { uint32_t u; _Float16 h[2]; } c; c.u = w; return (float)c.h[0]; };
+            auto hi_of = [](uint32_t w) { union { uint32_t u; _Float16 h[2]; } c; c.u = w; return (float)c.h[1]; };
+            const uint32_t pw[12] = {pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w, pc.x, pc.y, pc.z, pc.w};
+            float tn[4], tf[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+              const float x0 = __builtin_fmaf(lo_of(pw[3 * k]), ix, ax), x1 = __builtin_fmaf(hi_of(pw[3 * k]), ix, ax);
+              const float y0 = __builtin_fmaf(lo_of(pw[3 * k + 1]), iy, ay), y1 = __builtin_fmaf(hi_of(pw[3 * k + 1]), iy, ay);
+              const float z0 = __builtin_fmaf(lo_of(pw[3 * k + 2]), iz, az), z1 = __builtin_fmaf(hi_of(pw[3 * k + 2]), iz, az);
+              tn[k] = fmax_(fmax_(fmin_(x0, x1), fmin_(y0, y1)), vmax_(fmin_(z0, z1), tmin));
+              tf[k] = fmin_(fmin_(fmax_(x0, x1), fmax_(y0, y1)), vmin_(fmax_(z0, z1), tbest));
+            }
+            // slot references: family + (child byte turned so that its low nibble is the top of the word and its high nibble,
+            // the child's place in the family, the bottom)
+            const uint32_t family = hd.w & 0x00FFFFFFu;
+            uint32_t r0 = family + (__builtin_amdgcn_alignbit(hd.x, hd.x, 4) & 0xF000000Fu);
+            uint32_t r1 = family + (__builtin_amdgcn_alignbit(hd.y, hd.y, 4) & 0xF000000Fu);
+            uint32_t r2 = family + (__builtin_amdgcn_alignbit(hd.z, hd.z, 4) & 0xF000000Fu);
+            uint32_t r3 = family + (__builtin_amdgcn_alignbit(hd.w, hd.w, 28) & 0xF000000Fu);
+            const bool h0 = tn[0] <= tf[0], h1 = tn[1] <= tf[1], h2 = tn[2] <= tf[2], h3 = tn[3] <= tf[3];
+            uint32_t k0 = h0 ? ((__float_as_uint(tn[0]) & 0x7FFFFFFCu) | 0u) : 0xFFFFFFFFu;
+            uint32_t k1 = h1 ? ((__float_as_uint(tn[1]) & 0x7FFFFFFCu) | 1u) : 0xFFFFFFFFu;
+            uint32_t k2 = h2 ? ((__float_as_uint(tn[2]) & 0x7FFFFFFCu) | 2u) : 0xFFFFFFFFu;
+            uint32_t k3 = h3 ? ((__float_as_uint(tn[3]) & 0x7FFFFFFCu) | 3u) : 0xFFFFFFFFu;
+            const int n_hit = (int)h0 + (int)h1 + (int)h2 + (int)h3;
+#define RTGPU_CX(ka, ra, kb, rb) do { const bool sw_ = kb < ka; const uint32_t tk_ = sw_ ? kb : ka, tr_ = sw_ ? rb : ra; \
+                                       kb = sw_ ? ka : kb; rb = sw_ ? ra : rb; ka = tk_; ra = tr_; } while (0)
+            RTGPU_CX(k0, r0, k1, r1);
+            RTGPU_CX(k2, r2, k3, r3);
+            RTGPU_CX(k0, r0, k2, r2);
+            RTGPU_CX(k1, r1, k3, r3);
+            RTGPU_CX(k1, r1, k2, r2);
+#undef RTGPU_CX
+            cur = HYBRID ? stk.step4_hybrid(fast, n_hit, r0, r1, r2, r3, top) : stk.step4(n_hit, r0, r1, r2, r3, top);
+          }
+          if (!WIDE && !SLOTS) {
             // BVH2 node step in two halves, so that with R = 2 both rays' fetches are requested before either is tested
             struct NodeData { float4 q0, q1, q2; uint32_t c0, c1, top; };
             NodeData nd0, nd1;
@@ -1182,19 +1242,19 @@ void trace_kernel(const KParams P) {
             D.at_leaf = (int)cur < -1;
             D.at_sph = D.at_leaf && (cur & RTGPU_REF_SPHERE);
             D.at_tri = D.at_leaf && !(cur & RTGPU_REF_SPHERE);
-            D.i = RTGPU_REF_FIRST(cur);
+            D.i = cur & FIRST_MASK;
             D.fast = true;
             D.top = HYBRID ? S.stk.peek_hybrid(D.fast) : S.stk.peek();
             // a lane tests up to kTriStep of the triangles left in its leaf per step (all
             // records requested before the first test): same tests in the same order, fewer
             // dependent round trips
-            D.left = (cur >> 27) & 7u;                                    // triangles after this one
+            D.left = (cur >> CNT_SHIFT) & CNT_MASK;                        // triangles after this one
             D.more = TRIS > 1 && D.at_tri ? (D.left < (uint32_t)(TRIS - 1) ? D.left : (uint32_t)(TRIS - 1)) : 0u;
           };
           auto sph_fetch = [&](Ray &S, LeafData &D) __attribute__((always_inline)) {
             if (D.at_sph) {
               if (sph_in_lds) { const f4 w = sph_cache[D.i]; D.s = make_float4(w.x, w.y, w.z, w.w); }
-              else D.s = *(const float4 *)(sphs_base + (D.i << 4));
+              else D.s = *(const float4 *)(SLOTS ? nodes_base + (D.i << 6) : sphs_base + (D.i << 4));
             }
           };
           auto sph_test = [&](Ray &S, LeafData &D) __attribute__((always_inline)) {
@@ -1221,7 +1281,7 @@ void trace_kernel(const KParams P) {
               // C spelling back into v_mul_lo_u32, which is quarter rate.  32-bit offset: < 4 GiB of triangles
               uint32_t i3;
               asm("v_lshl_add_u32 %0, %1, 1, %1" : "=v"(i3) : "v"(D.i));
-              const float4 *tp = (const float4 *)(tris_base + (i3 << 4));
+              const float4 *tp = (const float4 *)(SLOTS ? nodes_base + (D.i << 6) : tris_base + (i3 << 4));  // (a slot per triangle)
 #pragma unroll
               for (int k = 0; k < TRIS; k++) {
                 if (TINY) {
@@ -1239,7 +1299,7 @@ void trace_kernel(const KParams P) {
                   // was a tenth of all the lane-loads of the S1 frame.  The loads of all k are still in flight together.
                   D.rec[k][0] = D.rec[k][1] = D.rec[k][2] = make_float4(0.f, 0.f, 0.f, 0.f);
                   if ((uint32_t)k <= D.more) {
-                    const float4 *tq = tp + 3u * (uint32_t)k;
+                    const float4 *tq = tp + (SLOTS ? 4u : 3u) * (uint32_t)k;
                     D.rec[k][0] = tq[0]; D.rec[k][1] = tq[1]; D.rec[k][2] = tq[2];
                   }
                 }
@@ -1269,7 +1329,7 @@ void trace_kernel(const KParams P) {
                   // the leaf cursor as it stands at this test: first + k, count - k
                   if (valid && t > tmin && t < S.tbest) {
                     S.tbest = t;
-                    S.hit_ref = S.cur + (uint32_t)k - ((uint32_t)k << 27);
+                    S.hit_ref = S.cur + (uint32_t)k - ((uint32_t)k << CNT_SHIFT);
                     S.hit_mat = __float_as_uint(b.w);
                     if (KEEP_N) { S.hit_n = cross(e1, e2); S.hit_prim = __float_as_uint(a.w); }
                   }
@@ -1280,7 +1340,7 @@ void trace_kernel(const KParams P) {
           auto leaf_advance = [&](Ray &S, LeafData &D) __attribute__((always_inline)) {
             if (D.at_leaf) {
               const bool last_now = D.left == D.more;
-              uint32_t next = S.cur + (D.more + 1u) - ((D.more + 1u) << 27);  // first+1, count-1 per test
+              uint32_t next = S.cur + (D.more + 1u) - ((D.more + 1u) << CNT_SHIFT);  // first+1, count-1 per test
               uint32_t popped = HYBRID ? S.stk.pop_if_hybrid(D.fast, last_now, D.top) : S.stk.pop_if(last_now, D.top);
               S.cur = last_now ? popped : next;
             }
@@ -1505,6 +1565,11 @@ struct rtgpu_ctx {
   void *d_nodes4_pad = nullptr; size_t nodes4_pad_bytes = 0;
   bool pad_valid = false;
   int pad_nodes4 = -1;          // RTGPU_NODE4_PAD=0/1 forces the choice; -1: by the size of the tree (kPadMinBytes)
+  // the slot tree (rtgpu_format.h; modes 11, 12): made from d_nodes4 and the primitive arrays by the first frame after an
+  // upload, build or refit.  slot_state: 0 not made yet, 1 valid, 2 this tree has no slot form (the four-wide nodes are used)
+  rtgpu::SlotTreeDevice slot;
+  int slot_state = 0;
+  int slot_tree = -1;           // RTGPU_SLOT_TREE=0/1 forces the choice; -1: kSlotTreeDefault
   uint32_t *d_refit_ws = nullptr; // refit scratch (3 u32 per node), allocated by the first refit of a scene
   rtgpu::DevPool pool;            // device memory kept between rtgpu_build_device calls (dev_pool.h)
   bool no_wide = false;         // RTGPU_NO_WIDE=1: keep the BVH2 traversal on large trees (experiments)
@@ -1561,12 +1626,12 @@ namespace {
 // code path; the threshold only changes WHEN finished lanes are refilled, never
 // what a path computes.  RTGPU_REFILL (0/20/40) selects it for experiments.
 using KernelFn = void (*)(const KParams);
-constexpr int kModes = 11;
-struct Variant { int refill; KernelFn fn[3][kModes]; };  // [plain, stats, profile][MODE 0..10 of trace_kernel]
+constexpr int kModes = 13;
+struct Variant { int refill; KernelFn fn[3][kModes]; };  // [plain, stats, profile][MODE 0..12 of trace_kernel]
 #define RTGPU_VARIANT_ROW(S, R)                                                                         \
   {trace_kernel<S, R, 0>, trace_kernel<S, R, 1>, trace_kernel<S, R, 2>, trace_kernel<S, R, 3>, trace_kernel<S, R, 4>, \
    trace_kernel<S, R, 5>, trace_kernel<S, R, 6>, trace_kernel<S, R, 7>, trace_kernel<S, R, 8>, trace_kernel<S, R, 9>, \
-   trace_kernel<S, R, 10>}
+   trace_kernel<S, R, 10>, trace_kernel<S, R, 11>, trace_kernel<S, R, 12>}
 #define RTGPU_VARIANT(R) {R, {RTGPU_VARIANT_ROW(0, R), RTGPU_VARIANT_ROW(1, R), RTGPU_VARIANT_ROW(2, R)}}
 #ifndef RTGPU_REFILL_SMALL
 #define RTGPU_REFILL_SMALL 20
@@ -1587,6 +1652,10 @@ constexpr bool kRays2Default = RTGPU_RAYS2_DEFAULT != 0;
 #ifndef RTGPU_PAD_MIN_MB
 #define RTGPU_PAD_MIN_MB 128
 #endif
+#ifndef RTGPU_SLOT_TREE_DEFAULT
+#define RTGPU_SLOT_TREE_DEFAULT 1
+#endif
+constexpr bool kSlotTreeDefault = RTGPU_SLOT_TREE_DEFAULT != 0;
 constexpr uint64_t kPadMinBytes = (uint64_t)RTGPU_PAD_MIN_MB << 20;  // four-wide node arrays from this size on are traversed in 128-byte slots  // MODE 8 for scenes that fit LDS whole (RTGPU_RAYS2 overrides)
 
 bool hip_fail(rtgpu_ctx *ctx, hipError_t e, const char *what) {
@@ -1608,6 +1677,7 @@ void free_scene_device(rtgpu_ctx *ctx) {
   ctx->d_nodes = ctx->d_tris = ctx->d_sphs = ctx->d_sph_meta = ctx->d_mats = ctx->d_nodes48 = ctx->d_nodes4 = nullptr;
   ctx->d_nodes4_src = nullptr;
   ctx->pad_valid = false;  // (the padded copy's memory is kept for the next scene)
+  ctx->slot_state = 0;     // (and the slot tree's)
   rtgpu::free_flat_scene(&ctx->host);
   ctx->have_scene = false;
   ctx->host_stale = false;
@@ -1709,6 +1779,7 @@ extern "C" int rtgpu_create(rtgpu_ctx **out, int device_index) {
   if (const char *env = std::getenv("RTGPU_NO_TINY")) ctx->no_tiny = std::atoi(env) != 0;
   if (const char *env = std::getenv("RTGPU_RAYS2")) ctx->rays2 = std::atoi(env) != 0 ? 1 : 0;
   if (const char *env = std::getenv("RTGPU_NODE4_PAD")) ctx->pad_nodes4 = std::atoi(env) != 0 ? 1 : 0;
+  if (const char *env = std::getenv("RTGPU_SLOT_TREE")) ctx->slot_tree = std::atoi(env) != 0 ? 1 : 0;
   if (const char *env = std::getenv("RTGPU_NO_MATS_CACHE")) ctx->no_mats_cache = std::atoi(env) != 0;
   if (const char *env = std::getenv("RTGPU_STACK_LDS")) {
     int want = std::atoi(env);
@@ -1752,6 +1823,7 @@ extern "C" void rtgpu_destroy(rtgpu_ctx *ctx) {
   (void)hipFree(ctx->d_wave_times);
   (void)hipFree(ctx->d_planes);
   (void)hipFree(ctx->d_nodes4_pad);
+  (void)hipFree(ctx->slot.d_slots);
   (void)hipFree(ctx->d_accum);
   (void)hipFree(ctx->d_ids);
   (void)hipFree(ctx->d_res_accum);
@@ -1995,6 +2067,7 @@ extern "C" int rtgpu_refit(rtgpu_ctx *ctx, const rtgpu_scene_desc *scene) {
   h.build_ms = ms;
   ctx->res_valid = false;  // new geometry: rtgpu_render_resolved starts its sum again (include/rtgpu.h)
   ctx->pad_valid = false;  // ... and the padded copy of the four-wide nodes is remade by the next frame
+  ctx->slot_state = 0;     // ... and the slot tree
   return 0;
 }
 
@@ -2034,6 +2107,7 @@ extern "C" int rtgpu_refit_device(rtgpu_ctx *ctx, const void *d_spheres, uint64_
   h.build_ms = ms;
   ctx->res_valid = false;  // new geometry: rtgpu_render_resolved starts its sum again (include/rtgpu.h)
   ctx->pad_valid = false;  // ... and the padded copy of the four-wide nodes is remade by the next frame
+  ctx->slot_state = 0;     // ... and the slot tree
   return 0;
 }
 
@@ -2259,6 +2333,21 @@ int launch_frame(rtgpu_ctx *ctx, const rtgpu_camera *cam, const rtgpu_settings *
     if (mode == 2 || mode >= 7) { ctx->err = "internal: packed nodes on a tree that fits the LDS cache"; return 2; }
     mode += wide ? 5 : 3;
   }
+  // The slot tree (modes 11, 12) in preference to the four-wide nodes it is made from, when this tree has one.  Made here, by
+  // the first frame after an upload / build / refit; the entry point that may not allocate uses it only if it exists already.
+  if ((mode == 5 || mode == 6) && !wide_cache) {
+    const bool want_slots = ctx->slot_tree >= 0 ? ctx->slot_tree != 0 : kSlotTreeDefault;
+    if (want_slots && ctx->slot_state == 0 && sc.may_allocate) {
+      if (rtgpu::build_slot_tree_device(ctx->d_nodes4, ctx->host.n_nodes4, ctx->d_tris, ctx->d_sphs, ctx->d_sph_meta, &ctx->slot,
+                                        &ctx->pool, (void *)stream, ctx->err))
+        return 2;
+      ctx->slot_state = ctx->slot.n_slots > 0 ? 1 : 2;
+    }
+    if (want_slots && ctx->slot_state == 1) {
+      P.nodes = (const float4 *)ctx->slot.d_slots;
+      mode += 6;  // 5 -> 11, 6 -> 12
+    }
+  }
   // Trees far larger than the caches: the four-wide nodes in 128-byte slots (modes 9, 10).  The padded copy is made here, by
   // the first frame after an upload / build / refit; the entry point that may not allocate uses it only if it exists already.
   if ((mode == 5 || mode == 6) && !wide_cache) {
@@ -2399,6 +2488,28 @@ extern "C" int rtgpu_debug_occupancy(rtgpu_ctx *ctx, uint64_t lds_bytes, int *bl
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, (const void *)kVariants[ctx->variant >= 0 ? ctx->variant : kVariantLargeTree].fn[0][1],
                                                             kBlock, (size_t)lds_bytes));
+  return 0;
+}
+
+// Diagnostics (not in the public header): the slot tree of the uploaded scene as the trace loop would traverse it (made now if
+// the last upload / build / refit has not been rendered yet).  *n_slots = 0: the scene has none (no four-wide nodes, or no
+// slot form).  Copies min(*n_slots, max_slots) slots of 16 words to out.
+extern "C" int rtgpu_debug_slot_tree(rtgpu_ctx *ctx, uint32_t *out, uint64_t max_slots, uint64_t *n_slots) {
+  if (!ctx || !n_slots) return 1;
+  *n_slots = 0;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  if (!ctx->d_nodes4) return 0;
+  if (ctx->slot_state == 0) {
+    if (rtgpu::build_slot_tree_device(ctx->d_nodes4, ctx->host.n_nodes4, ctx->d_tris, ctx->d_sphs, ctx->d_sph_meta, &ctx->slot,
+                                      &ctx->pool, nullptr, ctx->err))
+      return 2;
+    ctx->slot_state = ctx->slot.n_slots > 0 ? 1 : 2;
+  }
+  if (ctx->slot_state != 1) return 0;
+  *n_slots = ctx->slot.n_slots;
+  const uint64_t n = ctx->slot.n_slots < max_slots ? ctx->slot.n_slots : max_slots;
+  if (out && n) HIP_TRY(ctx, hipMemcpy(out, ctx->slot.d_slots, (size_t)n * 64, hipMemcpyDeviceToHost));
   return 0;
 }
 

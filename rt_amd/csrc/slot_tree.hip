@@ -1,0 +1,153 @@
+// slot_tree.hip — the slot tree (include/rtgpu_format.h) made on the GPU from the four-wide nodes and
+// the leaf-ordered primitive arrays of a context, whoever built them (host or device) and after every
+// refit.  Three passes over the four-wide nodes, one node per thread:
+//   1. slots each node's family (its children) takes; an exclusive scan numbers the families in the
+//      order of their parents, so a family is contiguous and every child lies after its parent;
+//   2. every inner child learns its slot from its parent;
+//   3. every node writes its own slot and copies the primitives of its leaf children into the family.
+// No reference counterpart (the reference has no BVH).
+#include <hip/hip_runtime.h>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/functional.hpp>
+
+#include <string>
+
+#include "dev_pool.h"
+#include "rtgpu_internal.h"
+#include "slot_tree.h"
+
+namespace {
+
+using rtgpu::SlotChild;
+
+__global__ __launch_bounds__(256) void family_sizes_kernel(const rtgpu_node4 *n4, uint32_t n, uint32_t *fam, uint32_t *bad) {
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+    const rtgpu_node4 nd = n4[i];
+    uint32_t size = 0;
+    for (int k = 0; k < 4; k++) {
+      SlotChild c;
+      if (!rtgpu::slot_child(nd, k, &c)) atomicOr(bad, 1u);
+      size += c.size;
+    }
+    fam[i] = size;
+  }
+}
+
+// family of node i = slots 1 + base[i] ...; slot_of[child] for its inner children (the root has slot 0)
+__global__ __launch_bounds__(256) void child_slots_kernel(const rtgpu_node4 *n4, uint32_t n, const uint32_t *base, uint32_t *slot_of,
+                                                          uint32_t *bad) {
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+    const rtgpu_node4 nd = n4[i];
+    uint32_t at = 1u + base[i];
+    if (i == 0) slot_of[0] = 0u;
+    for (int k = 0; k < 4; k++) {
+      SlotChild c;
+      (void)rtgpu::slot_child(nd, k, &c);
+      if (c.size && !(c.ref & RTGPU_REF_LEAF)) {
+        if (c.ref < n && c.ref > i) slot_of[c.ref] = at;
+        else atomicOr(bad, 2u);
+      }
+      at += c.size;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void write_slots_kernel(const rtgpu_node4 *n4, uint32_t n, const uint32_t *base, const uint32_t *slot_of,
+                                                          const uint4 *tris, const uint4 *sphs, const uint2 *sph_meta,
+                                                          uint4 *slots, uint32_t *bad) {
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+    const rtgpu_node4 nd = n4[i];
+    const uint32_t family = 1u + base[i];
+    uint32_t w[16];
+    if (!rtgpu::make_node_slot(nd, family, w)) { atomicOr(bad, 4u); continue; }
+    uint4 *dst = slots + 4 * (size_t)slot_of[i];
+    for (int q = 0; q < 4; q++) dst[q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+    uint32_t at = family;
+    for (int k = 0; k < 4; k++) {
+      SlotChild c;
+      (void)rtgpu::slot_child(nd, k, &c);
+      if (c.size && (c.ref & RTGPU_REF_LEAF)) {
+        const uint32_t first = RTGPU_REF_FIRST(c.ref);
+        for (uint32_t j = 0; j < c.size; j++) {
+          uint4 *p = slots + 4 * (size_t)(at + j);
+          if (c.ref & RTGPU_REF_SPHERE) {
+            const uint2 m = sph_meta[first + j];
+            p[0] = sphs[first + j];
+            p[1] = make_uint4(m.x, m.y, 0u, 0u);
+            p[2] = p[3] = make_uint4(0u, 0u, 0u, 0u);
+          } else {
+            const uint4 *t = tris + 3 * (size_t)(first + j);
+            p[0] = t[0]; p[1] = t[1]; p[2] = t[2];
+            p[3] = make_uint4(0u, 0u, 0u, 0u);
+          }
+        }
+      }
+      at += c.size;
+    }
+  }
+}
+
+}  // namespace
+
+namespace rtgpu {
+
+// The current device must be the context's.  Synchronous on `stream`.  Returns 0 with out->n_slots > 0 when the
+// slot tree was made, 0 with out->n_slots == 0 when this tree has no slot form (a leaf of more than four primitives,
+// a box more than 65504 wide, 2^24 slots or more), 2 on a HIP error.  out->d_slots is kept and reused (grow-only);
+// the temporaries come from `pool` when there is one (a loop that refits every frame asks for the same sizes each time).
+int build_slot_tree_device(const void *d_nodes4, uint64_t n4, const void *d_tris, const void *d_sphs, const void *d_sph_meta,
+                           SlotTreeDevice *out, DevPool *pool, void *stream_, std::string &err) {
+  hipStream_t stream = (hipStream_t)stream_;
+  out->n_slots = 0;
+  if (n4 == 0 || n4 >= (1ull << 24)) return 0;
+  const uint32_t n = (uint32_t)n4;
+  uint32_t *d_fam = nullptr, *d_base = nullptr, *d_slot_of = nullptr, *d_bad = nullptr;
+  void *d_tmp = nullptr;
+  size_t tmp_bytes = 0;
+  hipError_t e = dev_get(pool, (void **)&d_fam, (size_t)n * 4);
+  if (e == hipSuccess) e = dev_get(pool, (void **)&d_base, (size_t)n * 4);
+  if (e == hipSuccess) e = dev_get(pool, (void **)&d_slot_of, (size_t)n * 4);
+  if (e == hipSuccess) e = dev_get(pool, (void **)&d_bad, 4);
+  if (e == hipSuccess) e = hipMemsetAsync(d_bad, 0, 4, stream);
+  if (e == hipSuccess) e = rocprim::exclusive_scan(nullptr, tmp_bytes, d_fam, d_base, 0u, (size_t)n, rocprim::plus<uint32_t>(), stream);
+  if (e == hipSuccess) e = dev_get(pool, &d_tmp, tmp_bytes ? tmp_bytes : 64);
+  unsigned blocks = (unsigned)((n + 255u) / 256u);
+  if (blocks > 16384u) blocks = 16384u;
+  uint32_t last[2] = {0, 0}, bad = 0;
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(family_sizes_kernel, dim3(blocks), dim3(256), 0, stream, (const rtgpu_node4 *)d_nodes4, n, d_fam, d_bad);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = rocprim::exclusive_scan(d_tmp, tmp_bytes, d_fam, d_base, 0u, (size_t)n, rocprim::plus<uint32_t>(), stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(&last[0], d_base + (n - 1), 4, hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(&last[1], d_fam + (n - 1), 4, hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  const uint64_t n_slots = 1ull + last[0] + last[1];
+  bool usable = e == hipSuccess && !bad && n_slots < (1ull << 24);
+  if (usable) {
+    const size_t bytes = (size_t)n_slots * 64;
+    if (out->cap_bytes < bytes) {
+      (void)hipFree(out->d_slots);
+      out->d_slots = nullptr;
+      out->cap_bytes = 0;
+      e = hipMalloc(&out->d_slots, bytes);
+      if (e == hipSuccess) out->cap_bytes = bytes;
+    }
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(child_slots_kernel, dim3(blocks), dim3(256), 0, stream, (const rtgpu_node4 *)d_nodes4, n, d_base, d_slot_of, d_bad);
+      hipLaunchKernelGGL(write_slots_kernel, dim3(blocks), dim3(256), 0, stream, (const rtgpu_node4 *)d_nodes4, n, d_base, d_slot_of,
+                         (const uint4 *)d_tris, (const uint4 *)d_sphs, (const uint2 *)d_sph_meta, (uint4 *)out->d_slots, d_bad);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    usable = e == hipSuccess && !bad;
+  }
+  dev_put(pool, d_fam); dev_put(pool, d_base); dev_put(pool, d_slot_of); dev_put(pool, d_bad); dev_put(pool, d_tmp);
+  if (e != hipSuccess) { err = std::string("slot tree: ") + hipGetErrorString(e); return 2; }
+  if (usable) out->n_slots = n_slots;
+  return 0;
+}
+
+}  // namespace rtgpu

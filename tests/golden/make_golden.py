@@ -259,7 +259,7 @@ def make_mesh(o):
     fs = ra.FlatScene.build(scene)
     assert fs.c.nodes4 and fs.c.nodes48
     st = ra.default_settings(64, 36, spp=2, max_depth=8)
-    acc, ids, stats = o.render(fs.c, cam, st)
+    acc, ids, stats = o.render(fs.c, cam, st, slot_tree=False)
     np.savez_compressed(os.path.join(HERE, "s1_level5_64x36.npz"), ids=ids, accum_2spp=acc.view(np.uint32),
                         stats=np.array([stats[k] for k in sorted(stats)], np.uint64),
                         stats_keys=np.array(sorted(stats)),
@@ -269,12 +269,28 @@ def make_mesh(o):
     print("wrote s1_level5_64x36.npz")
 
 
+def make_mesh_slots(o):
+    # the same scene through its slot tree (include/rtgpu_format.h), which the trace loop traverses in
+    # preference to the four-wide nodes: the array itself, and the frame with its counters
+    scene, cam = ra.Scene.builtin(1, param=5, aspect=64 / 36)
+    fs = ra.FlatScene.build(scene)
+    slots = o.slot_tree(fs.c)
+    assert slots is not None
+    st = ra.default_settings(64, 36, spp=2, max_depth=8)
+    acc, ids, stats = o.render(fs.c, cam, st, slot_tree=True)
+    np.savez_compressed(os.path.join(HERE, "s1_level5_64x36_slots.npz"), ids=ids, accum_2spp=acc.view(np.uint32),
+                        stats=np.array([stats[k] for k in sorted(stats)], np.uint64),
+                        stats_keys=np.array(sorted(stats)),
+                        n_slots=np.array([slots.shape[0]], np.uint64),
+                        slots_fnv=np.array([fnv1a_fast(slots)], np.uint64),
+                        root=slots[0], first_family=slots[1:int(slots[0, 3] & 0xFFFFFF) + 4])
+    print("wrote s1_level5_64x36_slots.npz")
+
+
 if __name__ == "__main__":
     o = Oracle()
-    make_ref_math()
-    make_rng(o)
-    make_isect(o)
-    make_scatter(o)
-    make_images(o)
-    make_lit_box(o)
-    make_mesh(o)
+    makers = {"ref_math": make_ref_math, "rng": lambda: make_rng(o), "isect": lambda: make_isect(o),
+              "scatter": lambda: make_scatter(o), "images": lambda: make_images(o), "lit_box": lambda: make_lit_box(o),
+              "mesh": lambda: make_mesh(o), "mesh_slots": lambda: make_mesh_slots(o)}
+    for name in (sys.argv[1:] or list(makers)):   # all of them, or the ones named
+        makers[name]()

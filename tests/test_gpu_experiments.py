@@ -8,18 +8,26 @@ from util import assert_bit_equal
 
 pytestmark = pytest.mark.gpu
 
-# switch -> kernel mode expected on (S0: the whole scene fits LDS, a mesh with a four-wide tree in memory)
+# switch -> kernel mode expected on (S0: the whole scene fits LDS, a mesh whose tree lives in memory: its slot tree, or with
+# RTGPU_SLOT_TREE=0 the four-wide nodes the slot tree is made from)
 CASES = [
-    ({}, ((7, 8), 6)),                                              # (7 or 8: whichever the build makes the default)
-    ({"RTGPU_NO_TINY": "1"}, (2, 6)),                               # the tree in LDS, spheres behind it
-    ({"RTGPU_NO_SPHERE_CACHE": "1"}, (2, 6)),                       # the tree in LDS, spheres through L1
-    ({"RTGPU_RAYS2": "1"}, (8, 6)),                                 # two rays per lane in lock step (scenes in LDS)
-    ({"RTGPU_RAYS2": "0"}, (7, 6)),                                 # one ray per lane
-    ({"RTGPU_NODE4_PAD": "1"}, (7, 10)),                            # four-wide nodes in 128-byte slots (what huge trees run on)
+    ({}, ((7, 8), 12)),                                             # (7 or 8: whichever the build makes the default)
+    ({"RTGPU_NO_TINY": "1"}, (2, 12)),                              # the tree in LDS, spheres behind it
+    ({"RTGPU_NO_SPHERE_CACHE": "1"}, (2, 12)),                      # the tree in LDS, spheres through L1
+    ({"RTGPU_RAYS2": "1"}, (8, 12)),                                # two rays per lane in lock step (scenes in LDS)
+    ({"RTGPU_RAYS2": "0"}, (7, 12)),                                # one ray per lane
+    ({"RTGPU_STACK_LDS": "14"}, (7, 11)),                           # the deeper stack entries in memory
+    ({"RTGPU_REFILL": "0"}, (7, 12)),                               # plain while-while traversal rounds
+    ({"RTGPU_NO_MATS_CACHE": "1"}, (7, 12)),                        # trees in memory: materials through L1, not LDS
+]
+# the same over the four-wide nodes: their boxes are tighter than the slot tree's halves, so the counters of node visits and
+# triangle tests are smaller, and equal among these; frame and ids are the slot tree's
+WIDE = {"RTGPU_SLOT_TREE": "0"}
+WIDE_CASES = [
+    ({}, (7, 6)),
+    ({"RTGPU_NODE4_PAD": "1"}, (7, 10)),                            # four-wide nodes in 128-byte slots
     ({"RTGPU_NODE4_PAD": "1", "RTGPU_STACK_LDS": "14"}, (7, 9)),    # ... with the deeper stack entries in memory
     ({"RTGPU_WIDE_CACHE": "1"}, (7, 5)),                            # experiment A: top of the four-wide tree in LDS
-    ({"RTGPU_REFILL": "0"}, (7, 6)),                                # plain while-while traversal rounds
-    ({"RTGPU_NO_MATS_CACHE": "1"}, (7, 6)),                         # trees in memory: materials through L1, not LDS
 ]
 
 
@@ -34,20 +42,48 @@ def _frames(ra, ctx):
     return out
 
 
-@pytest.mark.parametrize("env,modes", CASES[1:], ids=lambda v: "+".join(v) if isinstance(v, dict) else None)
-def test_experiment_switches_leave_the_frame_alone(ra, gpu_ctx, monkeypatch, env, modes):
-    want = _frames(ra, gpu_ctx)
-    assert want[0][3] in CASES[0][1][0] and want[1][3] == CASES[0][1][1]
+def _frames_with(ra, monkeypatch, env):
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     ctx = ra.Context(0)
     try:
-        got = _frames(ra, ctx)
+        return _frames(ra, ctx)
     finally:
         ctx.close()
+        for k in env:
+            monkeypatch.delenv(k)
+
+
+@pytest.mark.parametrize("env,modes", CASES[1:], ids=lambda v: "+".join(v) if isinstance(v, dict) else None)
+def test_experiment_switches_leave_the_frame_alone(ra, gpu_ctx, monkeypatch, env, modes):
+    want = _frames(ra, gpu_ctx)
+    assert want[0][3] in CASES[0][1][0] and want[1][3] == CASES[0][1][1]
+    got = _frames_with(ra, monkeypatch, env)
     if modes[0] == 7 and "RTGPU_RAYS2" not in env:
         modes = (want[0][3], modes[1])                           # the switch leaves the choice between 7 and 8 alone
     assert tuple(f[3] for f in got) == modes
     for (a, ia, sa, _), (b, ib, sb, _) in zip(got, want):
         assert_bit_equal(a, b, f"{env}")
         assert np.array_equal(ia, ib) and sa == sb
+
+
+@pytest.mark.parametrize("env,modes", WIDE_CASES, ids=lambda v: ("wide+" + "+".join(v)) if isinstance(v, dict) else None)
+def test_four_wide_nodes_give_the_slot_trees_frame(ra, oracle, gpu_ctx, monkeypatch, env, modes):
+    want = _frames(ra, gpu_ctx)
+    base = _frames_with(ra, monkeypatch, WIDE)
+    got = _frames_with(ra, monkeypatch, {**WIDE, **env})
+    assert tuple(f[3] for f in got) == (want[0][3], modes[1])
+    for (a, ia, sa, _), (b, ib, sb, _), (c, ic, sc, _) in zip(got, base, want):
+        assert_bit_equal(a, b, f"{env}")
+        assert np.array_equal(ia, ib) and sa == sb               # among the four-wide modes: everything
+        assert_bit_equal(a, c, f"{env} vs slot tree")             # against the slot tree: frame and ids ...
+        assert np.array_equal(ia, ic)
+        assert {k: sa[k] for k in ("paths", "rays", "scatters")} == {k: sc[k] for k in ("paths", "rays", "scatters")}
+    assert got[1][2]["nodes"] < want[1][2]["nodes"]               # ... with fewer node visits
+    # and the oracle over the four-wide nodes agrees with the kernel over them, counters included
+    scene, cam = ra.Scene.builtin(1, param=5, aspect=128 / 72)
+    fs = ra.FlatScene.build(scene)
+    st = ra.default_settings(128, 72, spp=3, max_depth=8, seed=11, flags=ra.FLAG_STATS)
+    o, io, so = oracle.render(fs.c, cam, st, slot_tree=False, threads=8)
+    assert_bit_equal(got[1][0], o, "oracle over the four-wide nodes")
+    assert np.array_equal(got[1][1], io) and got[1][2] == so

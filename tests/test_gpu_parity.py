@@ -80,16 +80,23 @@ def test_golden_fixture_without_oracle(ra, gpu_ctx):
     assert fs.c.n_nodes == chk["flat_s0"]["n_nodes"]
 
 
-def test_large_tree_fixture_without_oracle(ra, gpu_ctx):
-    """Committed vectors only: S1 level 5 through the four-wide nodes (kernel mode 6)."""
+def test_large_tree_fixture_without_oracle(ra, monkeypatch):
+    """Committed vectors only: S1 level 5 - the four-wide nodes as flattened here, and the frame through them (kernel
+    mode 6; by default the trace loop takes the slot tree made from them: tests/test_gpu_slot_tree.py)."""
     if os.environ.get("RTGPU_NO_WIDE"):
         pytest.skip("asserts the four-wide nodes that RTGPU_NO_WIDE switches off")
     g = np.load(f"{GOLDEN}/s1_level5_64x36.npz")
     scene, cam = ra.Scene.builtin(1, param=5, aspect=64 / 36)
-    gpu_ctx.upload(scene)
-    fs = gpu_ctx.flat_scene()
-    assert [fs.c.n_nodes, fs.c.n_nodes4, fs.c.max_stack4] == g["n_nodes"].tolist()
-    a, ids, st = gpu_ctx.render(cam, ra.default_settings(64, 36, spp=2, max_depth=8, flags=ra.FLAG_STATS))
+    monkeypatch.setenv("RTGPU_SLOT_TREE", "0")
+    ctx = ra.Context(0)
+    try:
+        ctx.upload(scene)
+        fs = ctx.flat_scene()
+        assert [fs.c.n_nodes, fs.c.n_nodes4, fs.c.max_stack4] == g["n_nodes"].tolist()
+        a, ids, st = ctx.render(cam, ra.default_settings(64, 36, spp=2, max_depth=8, flags=ra.FLAG_STATS))
+        _assert_mode(ctx, 6)
+    finally:
+        ctx.close()
     assert np.array_equal(ids, g["ids"]) and np.array_equal(bits(a), g["accum_2spp"])
     assert [st.as_dict()[k] for k in sorted(st.as_dict())] == g["stats"].tolist()
 

@@ -1,0 +1,136 @@
+"""The slot tree (include/rtgpu_format.h; kernel modes 11 and 12) on the GPU: the array slot_tree.hip makes from the
+four-wide nodes and the primitive arrays is the oracle's restatement byte for byte - for trees of both builders,
+for spheres and triangles in one tree, after a refit - frames traced through it match the oracle's bit for bit with
+their counters, and a tree that has no slot form runs on the four-wide nodes."""
+import numpy as np
+import pytest
+
+from util import GOLDEN, assert_bit_equal, bits, fnv1a_words, make_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def _mode(ctx):
+    return int(ctx.kernel_name().rstrip(">").split(",")[-1])
+
+
+def _mixed(ra, seed=6, n_sph=1200, n_tri=1200):
+    """Overlapping spheres and triangles with all three scattering materials (the soup of test_gpu_parity)."""
+    rng = np.random.default_rng(seed)
+    mats = [(0, .8, .6, .4, 0.0), (1, .9, .9, .7, 0.2), (2, 1., 1., 1., 1.5), (0, .3, .5, .8, 0.0), (1, .7, .7, .7, 0.0)]
+    sph = [(*rng.uniform(-3, 3, 3).tolist(), float(rng.uniform(0.05, 0.5)), int(rng.integers(0, 5))) for _ in range(n_sph)]
+    tri = []
+    for _ in range(n_tri):
+        c = rng.uniform(-3, 3, 3)
+        tri.append((tuple(c + rng.normal(0, .4, 3)), tuple(c + rng.normal(0, .4, 3)), tuple(c + rng.normal(0, .4, 3)),
+                    int(rng.integers(0, 5))))
+    return make_scene(ra, spheres=sph, triangles=tri, materials=mats)
+
+
+@pytest.mark.parametrize("builder", ["sah", "lbvh"])
+def test_device_slot_tree_is_the_oracles(ra, oracle, gpu_ctx, builder):
+    scenes = {"S1 level 5": ra.Scene.builtin(1, param=5)[0], "S2 level 4": ra.Scene.builtin(2, param=4)[0],
+              "spheres and triangles": _mixed(ra)}
+    for name, scene in scenes.items():
+        gpu_ctx.upload(scene, builder=builder)
+        fs = gpu_ctx.flat_scene()
+        assert fs.c.nodes4, name
+        got = gpu_ctx.debug_slot_tree()
+        want = oracle.slot_tree(fs.c)
+        assert got is not None and want is not None and got.shape == want.shape, name
+        assert np.array_equal(got, want), f"{name} / {builder}: slot {np.nonzero((got != want).any(axis=1))[0][:5]} differ"
+        if name == "S1 level 5" and builder == "sah":   # ... and the committed one
+            g = np.load(f"{GOLDEN}/s1_level5_64x36_slots.npz")
+            assert got.shape[0] == int(g["n_slots"][0]) and fnv1a_words(got) == int(g["slots_fnv"][0])
+
+
+def test_slot_tree_fixture_without_oracle(ra, gpu_ctx):
+    """Committed vectors only: S1 level 5 through its slot tree (kernel mode 12)."""
+    g = np.load(f"{GOLDEN}/s1_level5_64x36_slots.npz")
+    scene, cam = ra.Scene.builtin(1, param=5, aspect=64 / 36)
+    gpu_ctx.upload(scene)
+    a, ids, st = gpu_ctx.render(cam, ra.default_settings(64, 36, spp=2, max_depth=8, flags=ra.FLAG_STATS))
+    assert _mode(gpu_ctx) == 12
+    assert np.array_equal(ids, g["ids"]) and np.array_equal(bits(a), g["accum_2spp"])
+    assert [st.as_dict()[k] for k in sorted(st.as_dict())] == g["stats"].tolist()
+
+
+@pytest.mark.parametrize("builder", ["sah", "lbvh"])
+def test_frames_through_the_slot_tree(ra, oracle, gpu_ctx, builder):
+    """Spheres (their ids and materials ride in the slot), triangles in leaves of one to four, glass and metal; the
+    LDS-only stack (mode 12) and, with a shallow LDS share, the stack that spills to memory (mode 11)."""
+    scene = _mixed(ra)
+    cam = ra.look_at((0.5, 1.0, 9.0), (0, 0, 0), vfov=50.0, aspect=1.5)
+    st = ra.default_settings(120, 80, spp=3, max_depth=6, seed=5, flags=ra.FLAG_STATS)
+    gpu_ctx.upload(scene, builder=builder)
+    a, ia, sa = gpu_ctx.render(cam, st)
+    assert _mode(gpu_ctx) == 12
+    b, ib, sb = oracle.render(gpu_ctx.flat_scene().c, cam, st, threads=8)
+    assert_bit_equal(a, b, f"mixed scene / {builder}")
+    assert np.array_equal(ia, ib) and sa.as_dict() == sb
+    assert sb["sphere_tests"] > 0 and sb["tri_tests"] > 0 and len(np.unique(ia)) > 200
+
+
+def test_hybrid_stack_over_the_slot_tree(ra, oracle, monkeypatch):
+    monkeypatch.setenv("RTGPU_STACK_LDS", "10")
+    ctx = ra.Context(0)
+    try:
+        scene, cam = ra.Scene.builtin(2, param=4, aspect=1.5)
+        st = ra.default_settings(120, 80, spp=2, max_depth=8, seed=2, flags=ra.FLAG_STATS)
+        ctx.upload(scene)
+        a, ia, sa = ctx.render(cam, st)
+        assert _mode(ctx) == 11
+        b, ib, sb = oracle.render(ctx.flat_scene().c, cam, st, threads=8)
+        assert_bit_equal(a, b, "hybrid stack")
+        assert np.array_equal(ia, ib) and sa.as_dict() == sb
+    finally:
+        ctx.close()
+
+
+def test_slot_tree_follows_a_refit(ra, oracle, gpu_ctx):
+    from test_refit import _moved
+    scene, cam = ra.Scene.builtin(1, param=5, aspect=1.5)
+    moved = _moved(ra, scene)
+    st = ra.default_settings(96, 64, spp=2, max_depth=6, flags=ra.FLAG_STATS)
+    gpu_ctx.upload(scene)
+    first, _, _ = gpu_ctx.render(cam, st)
+    before = gpu_ctx.debug_slot_tree()
+    for how in ("host", "device"):
+        gpu_ctx.upload(scene)
+        gpu_ctx.render(cam, st)                              # the slot tree of the first geometry exists
+        if how == "host":
+            gpu_ctx.refit(moved)
+        else:
+            import torch
+            tri = torch.from_numpy(moved.triangles.view(np.uint8).copy()).cuda()
+            gpu_ctx.refit_device(None, 0, tri.data_ptr(), len(moved.triangles))
+        a, ia, sa = gpu_ctx.render(cam, st)
+        assert _mode(gpu_ctx) == 12
+        fs = gpu_ctx.flat_scene()
+        got, want = gpu_ctx.debug_slot_tree(), oracle.slot_tree(fs.c)
+        assert np.array_equal(got, want) and not np.array_equal(got, before), how
+        b, ib, sb = oracle.render(fs.c, cam, st, threads=8)
+        assert_bit_equal(a, b, f"after a {how} refit")
+        assert np.array_equal(ia, ib) and sa.as_dict() == sb
+        assert not np.array_equal(bits(a), bits(first))
+
+
+def test_tree_without_a_slot_form_runs_on_the_four_wide_nodes(ra, oracle, gpu_ctx):
+    """A scene 400 000 units wide: the top boxes are farther from their origin than binary16 reaches, so there is no slot
+    tree; kernel and oracle both traverse the four-wide nodes and agree, counters included."""
+    rng = np.random.default_rng(3)
+    tri = []
+    for _ in range(3000):
+        c = rng.uniform(-2e5, 2e5, 3)
+        tri.append((tuple(c + rng.normal(0, 3e3, 3)), tuple(c + rng.normal(0, 3e3, 3)), tuple(c + rng.normal(0, 3e3, 3)), 0))
+    scene = make_scene(ra, triangles=tri, materials=[(0, .7, .7, .7, 0)])
+    cam = ra.look_at((0, 0, 6e5), (0, 0, 0), vfov=50.0, aspect=1.5)
+    st = ra.default_settings(96, 64, spp=2, max_depth=4, flags=ra.FLAG_STATS)
+    gpu_ctx.upload(scene)
+    fs = gpu_ctx.flat_scene()
+    assert fs.c.nodes4 and oracle.slot_tree(fs.c) is None and gpu_ctx.debug_slot_tree() is None
+    a, ia, sa = gpu_ctx.render(cam, st)
+    assert _mode(gpu_ctx) == 6
+    b, ib, sb = oracle.render(fs.c, cam, st, threads=8)
+    assert_bit_equal(a, b, "no slot form")
+    assert np.array_equal(ia, ib) and sa.as_dict() == sb and (ia != 0xFFFFFFFF).sum() > 100

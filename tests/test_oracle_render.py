@@ -222,6 +222,77 @@ def test_large_tree_fixture(ra, oracle):
     assert [fs.c.n_nodes, fs.c.n_nodes4, fs.c.max_stack4] == g["n_nodes"].tolist()
     assert fnv1a_words(fs.nodes4_u32) == int(g["nodes4_fnv"][0])
     assert fnv1a_words(fs.nodes48_u32) == int(g["nodes48_fnv"][0])
-    acc, ids, stats = oracle.render(fs.c, cam, ra.default_settings(64, 36, spp=2, max_depth=8))
+    acc, ids, stats = oracle.render(fs.c, cam, ra.default_settings(64, 36, spp=2, max_depth=8), slot_tree=False)
     assert np.array_equal(ids, g["ids"]) and np.array_equal(bits(acc), g["accum_2spp"])
     assert [stats[k] for k in sorted(stats)] == g["stats"].tolist()
+
+
+def test_slot_tree_fixture(ra, oracle):
+    """The same scene through its slot tree (rtgpu_format.h): the committed array and frame; the frame is the
+    four-wide nodes' (the boxes only grow, by the rounding of their planes to binary16), the counters are not."""
+    g = np.load(f"{GOLDEN}/s1_level5_64x36_slots.npz")
+    g4 = np.load(f"{GOLDEN}/s1_level5_64x36.npz")
+    scene, cam = ra.Scene.builtin(1, param=5, aspect=64 / 36)
+    fs = ra.FlatScene.build(scene)
+    slots = oracle.slot_tree(fs.c)
+    assert slots.shape == (int(g["n_slots"][0]), 16) and fnv1a_words(slots) == int(g["slots_fnv"][0])
+    assert np.array_equal(slots[0], g["root"])
+    st = ra.default_settings(64, 36, spp=2, max_depth=8)
+    acc, ids, stats = oracle.render(fs.c, cam, st)                      # builds the tree itself
+    acc2, ids2, stats2 = oracle.render(fs.c, cam, st, slots=slots)      # traverses the one given
+    assert np.array_equal(ids, g["ids"]) and np.array_equal(bits(acc), g["accum_2spp"])
+    assert np.array_equal(ids, ids2) and np.array_equal(bits(acc), bits(acc2)) and stats == stats2
+    assert [stats[k] for k in sorted(stats)] == g["stats"].tolist()
+    assert np.array_equal(g["ids"], g4["ids"]) and np.array_equal(g["accum_2spp"], g4["accum_2spp"])
+    want4 = dict(zip(g4["stats_keys"].tolist(), g4["stats"].tolist()))
+    assert stats["nodes"] > want4["nodes"] and stats["rays"] == want4["rays"] and stats["scatters"] == want4["scatters"]
+
+
+def test_slot_tree_structure(ra, oracle):
+    """Every slot of the tree is reached exactly once from the root, every child box (origin + halves) contains the
+    four-wide node's box for that child, and the primitives in the slots are the leaf-ordered arrays' records."""
+    for kind, param in ((1, 5), (2, 4)):
+        scene, _ = ra.Scene.builtin(kind, param=param, aspect=1.5)
+        fs = ra.FlatScene.build(scene)
+        slots = oracle.slot_tree(fs.c)
+        n4 = fs.nodes4_u32.reshape(-1, 24)
+        tris = np.frombuffer(ra.api.C.string_at(fs.c.tris, fs.c.n_tris * 48), np.uint32).reshape(-1, 12)
+        seen = np.zeros(len(slots), np.int32)
+        # walk both trees together: (slot, four-wide node)
+        todo = [(0, 0)]
+        while todo:
+            s, i = todo.pop()
+            seen[s] += 1
+            w = slots[s]
+            org = w[:3].view(np.float32).astype(np.float64)
+            family = int(w[3] & 0xFFFFFF)
+            byte = [int(w[0] & 0xFF), int(w[1] & 0xFF), int(w[2] & 0xFF), int(w[3] >> 24)]
+            at = 0
+            for k in range(4):
+                cw = n4[i, 6 * k:6 * k + 6]
+                ref = int(cw[0] & 0xFF) | int(cw[1] & 0xFF) << 8 | int(cw[2] & 0xFF) << 16 | int(cw[3] & 0xFF) << 24
+                halves = w[4 + 3 * k:7 + 3 * k]
+                if ref == 0xFFFFFFFF:
+                    assert all(int(h) == 0x7C007C00 for h in halves) and byte[k] == at << 4
+                    continue
+                lo = (halves & 0xFFFF).astype(np.uint16).view(np.float16).astype(np.float64) + org
+                hi = (halves >> 16).astype(np.uint16).view(np.float16).astype(np.float64) + org
+                box = cw.view(np.float32).astype(np.float64)
+                assert (lo <= box[:3]).all() and (hi >= box[3:]).all()
+                # ... and tight: within 2^-10 of the offset (a binary16 step) or of the smallest normal half
+                assert ((box[:3] - lo) <= np.maximum((box[:3] - org) * 2.0 ** -10, 2.0 ** -14)).all()
+                assert ((hi - box[3:]) <= np.maximum((box[3:] - org) * 2.0 ** -10, 2.0 ** -14)).all()
+                assert byte[k] >> 4 == at
+                if ref & 0x80000000:
+                    count = ((ref >> 27) & 7) + 1
+                    assert byte[k] & 0xF == 8 | (4 if ref & 0x40000000 else 0) | (count - 1)
+                    for j in range(count):
+                        seen[family + at + j] += 1
+                        if not ref & 0x40000000:
+                            assert np.array_equal(slots[family + at + j, :12], tris[(ref & 0x07FFFFFF) + j])
+                    at += count
+                else:
+                    assert byte[k] & 0xF == 0
+                    todo.append((family + at, ref))
+                    at += 1
+        assert (seen == 1).all()

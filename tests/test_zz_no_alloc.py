@@ -57,7 +57,7 @@ def test_static_scratch_entry_point(ra, oracle):
         # one chunk needs no planes at all: a frame of any size
         one = ra.default_settings(1920, 1080, spp=2, max_depth=8, chunk_samples=2)
         _pair(ra, ctx, ra.look_at((13, 2, 3), (0, 0, 0), vfov=20.0, aspect=16 / 9), one)
-        # a large tree through the four-wide nodes (kernel mode 6), two chunks
+        # a large tree (its slot tree, kernel mode 12: made by the allocating call of the pair, found there by the other), two chunks
         mesh, cam_m = ra.Scene.builtin(1, param=6, aspect=16 / 9)
         ctx.upload(mesh)
         _pair(ra, ctx, cam_m, ra.default_settings(640, 360, spp=4, max_depth=8, flags=ra.FLAG_STATS))
