@@ -53,8 +53,8 @@ VALU_ISSUE_PEAK_GINST = 1228.8  # the same peak in wave64 instructions: 1024 SIM
 
 
 def algorithmic_bytes(st, n_pixels, node_bytes):
-    """SURVEY.md §8d.  node_bytes: 64 (BVH2 nodes; the C2 tree, read from its LDS copy), 48
-    (packed BVH2 nodes) or 96 (four-wide nodes) - what one node step of the launched mode reads."""
+    """SURVEY.md §8d.  node_bytes: 64 (BVH2 nodes - the C2 tree, read from its LDS copy - or the node slots of the
+    slot tree), 48 (packed BVH2 nodes) or 96 (four-wide nodes) - what one node step of the launched mode reads."""
     return node_bytes * st["nodes"] + 48 * st["tri_tests"] + 16 * st["sphere_tests"] + 32 * st["scatters"] + 16 * n_pixels
 
 
@@ -78,13 +78,28 @@ def committed_pmc(name, width, height, spp, depth):
     return wl, doc.get("ubench", {})
 
 
+def kernel_mode(kernel):
+    """MODE of a 'trace_kernel<STATS,REFILL,MODE>' name, or None."""
+    try:
+        return int(kernel.rstrip(">").split(",")[-1]) if kernel.startswith("trace_kernel<") else None
+    except ValueError:
+        return None
+
+
 def node_bytes_of(ctx):
+    """Bytes one node step of the LAST launch read (call after a frame)."""
+    mode = kernel_mode(ctx.kernel_name())
+    if mode in (11, 12):          # the slot tree: 64-byte node slots
+        return 64
     c = ctx.flat_scene().c
     return 96 if c.nodes4 else 48 if c.nodes48 else 64
 
 
-def roofline_block(bound, counts, n_px, node_bytes, k_ms, kernel, pmc, ub):
-    """The roofline object of one launch: `bound` as SURVEY.md §8d names it for the workload."""
+def roofline_block(bound, counts, n_px, node_bytes, k_ms, kernel, pmc, ub, in_memory=None):
+    """The roofline object of one launch: `bound` as SURVEY.md §8d names it for the workload.
+    in_memory: the tree is fetched through the vector memory pipeline (default: by the kernel's mode)."""
+    if in_memory is None:
+        in_memory = kernel_mode(kernel) not in (None, 2, 7, 8)
     sec = k_ms * 1e-3
     abytes = algorithmic_bytes(counts, n_px, node_bytes)
     aflops = algorithmic_flops(counts)
@@ -101,22 +116,23 @@ def roofline_block(bound, counts, n_px, node_bytes, k_ms, kernel, pmc, ub):
                    "LDS, L1 and L2 - informational, never a fraction of HBM"}
     vmem = None
     caps = ub.get("vmem_records_per_cycle_per_cu") or {}
-    if node_bytes != 64 and caps.get("node96_l2") and caps.get("tri48_l2"):
+    if in_memory and caps.get("node96_l2") and caps.get("node64_l2") and caps.get("tri48_l2"):
         # Trees in memory: what the vector memory pipeline (TA / L1) can deliver for THIS access pattern - every lane its own
         # record, 16 bytes per lane and load.  tools/ubench/node_fetch.hip measures records per cycle per CU by record shape;
         # the floor of the launch is its node visits and triangle tests at those rates (tables that fit one L2: an upper
         # bound on the rate, since part of the real fetches miss L2).
         cus, clk = 256, 2.4e9
-        node_cap = caps["node96_l2"] if node_bytes == 96 else caps.get("tri48_l2")   # packed 48-byte BVH2 nodes fetch like triangles
+        node_cap = caps["node96_l2"] if node_bytes == 96 else caps["node64_l2"] if node_bytes == 64 else caps["tri48_l2"]   # (packed 48-byte BVH2 nodes fetch like triangles)
         floor_s = (counts["nodes"] / node_cap + counts["tri_tests"] / caps["tri48_l2"]) / cus / clk
         vmem = {"records_per_launch": counts["nodes"] + counts["tri_tests"],
                 "achieved_records_per_cycle_per_cu": round((counts["nodes"] + counts["tri_tests"]) / (sec * clk * cus), 4),
                 "peak_node_records_per_cycle_per_cu": node_cap, "peak_triangle_records_per_cycle_per_cu": caps["tri48_l2"],
                 "floor_ms": round(floor_s * 1e3, 3), "frac": round(floor_s / sec, 3), "source": ub.get("vmem_source"),
-                "note": "the bound that binds these scenes: one random record per lane and step through the vector L1 (16 B per lane "
-                        "and load; ~0.7 cycle per lane-load).  frac = time the launch's record fetches need at the measured peak rate / "
-                        "kernel time.  The HBM fraction above is what the contract's `bound` asks for; this is the roofline the kernel "
-                        "actually runs against (DESIGN.md §5.2)."}
+                "note": "the vector memory pipeline's ceiling for this access pattern: one random record per lane and step through the "
+                        "vector L1 (16 B per lane and load; ~0.7 cycle per lane-load), at the rate of tables that fit one L2.  frac = time "
+                        "the launch's record fetches need at that rate / kernel time.  The HBM fraction above is what the contract's "
+                        "`bound` asks for; this and valu_issue are the two ceilings the kernel runs under, neither saturated: what is "
+                        "left is latency that four waves per SIMD do not cover (DESIGN.md §5.2)."}
     out = {"bound": bound, "traffic": traffic, "traffic_source": pmc.get("source") if pmc else None,
            "kernel": kernel, "kernel_ms": round(k_ms, 4),
            "kernel_mrays_per_s": round(counts["rays"] / sec / 1e6, 1), "valu": valu, "hbm": hbm, "vmem": vmem}
@@ -151,8 +167,10 @@ def cpu_baseline(flat_c, cam, label, width, height, depth, sample_spp, frame_spp
     cores = min(len(os.sched_getaffinity(0)), 16)
     st = ra.default_settings(width, height, spp=sample_spp, max_depth=depth)
     o = Oracle()
+    # what the GPU traverses: the slot tree when the scene has one - made once, outside the timed calls, like the GPU's
+    slots = o.slot_tree(flat_c) if flat_c.nodes4 else None
     t0 = time.perf_counter()
-    _, _, stats = o.render(flat_c, cam, st, threads=cores, want_ids=False)
+    _, _, stats = o.render(flat_c, cam, st, threads=cores, want_ids=False, slots=slots, slot_tree=False)
     dt = time.perf_counter() - t0
     out = {
         "value": round(stats["rays"] / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
@@ -163,7 +181,7 @@ def cpu_baseline(flat_c, cam, label, width, height, depth, sample_spp, frame_spp
         # the reference program is single-threaded by design: one core, 1 spp
         st1 = ra.default_settings(width, height, spp=1, max_depth=depth)
         t0 = time.perf_counter()
-        _, _, stats1 = o.render(flat_c, cam, st1, threads=1, want_ids=False)
+        _, _, stats1 = o.render(flat_c, cam, st1, threads=1, want_ids=False, slots=slots, slot_tree=False)
         dt1 = time.perf_counter() - t0
         out["one_core"] = {"value": round(stats1["rays"] / dt1 / 1e6, 3), "unit": "Mrays/s", "cores": 1,
                            "sample": f"1 spp of the same frame: {stats1['rays']} rays in {dt1:.2f} s"}
@@ -326,8 +344,9 @@ def run_group(args, torch, ra, share_gpu):
     g.close()
     pmc, ub = committed_pmc(config, W, H, spp_arg, depth)
     per_rank = {k: v // world for k, v in counts.items()}
-    node_bytes = 96 if kind != 0 else 64
-    roof = roofline_block(bound, per_rank, W * H // world, node_bytes, k_ms, "trace_kernel (slowest rank's last frame)", None, ub)
+    node_bytes = 64   # S0: the tree's LDS copy; trees in memory: the node slots of the slot tree
+    roof = roofline_block(bound, per_rank, W * H // world, node_bytes, k_ms, "trace_kernel (slowest rank's last frame)", None, ub,
+                          in_memory=kind != 0)
     roof["estimated_from_single_gpu_pass"] = estimate_for_rank(pmc, world)
     how = (f", native group: one process, {world} worker threads, "
            + (f"RCCL communicator of {ranks} ranks (ncclCommInitAll), ncclSend / ncclRecv to GPU {devices[0]}" if ranks

@@ -53,7 +53,8 @@ def main():
             ms.append(ctx.kernel_ms())
         ms = np.array(ms)
         wide = f"/{fs.c.n_nodes4}x4" if fs.c.nodes4 else ""
-        node_bytes = 96 if fs.c.nodes4 else 48 if fs.c.nodes48 else 64   # four-wide / packed nodes from RTGPU_NODE48_MIN_NODES up
+        slot_tree = ctx.kernel_name().rstrip(">").split(",")[-1] in ("11", "12")
+        node_bytes = 64 if slot_tree else 96 if fs.c.nodes4 else 48 if fs.c.nodes48 else 64   # slot tree / four-wide / packed nodes
         abytes = node_bytes * s["nodes"] + 48 * s["tri_tests"] + 16 * s["sphere_tests"] + 32 * s["scatters"] + 16 * w * h
         print(f"{name}: prims={scene.n_prims} nodes={fs.c.n_nodes}{wide} depth={fs.c.max_depth} gen={t1-t0:.1f}s "
               f"build+upload={t2-t1:.1f}s (bvh {fs.c.build_ms:.1f} ms) | {w}x{h}x{spp} rays={s['rays']} "
