@@ -28,7 +28,7 @@ for name, kind, param, w, h, spp in CASES:
         same = (np.array_equal(ids, want_ids) and np.array_equal(acc.view(np.uint32), want.view(np.uint32))
                 and stats.as_dict() == want_stats)
         ok &= same
-        print(f"{name} {builder}: {w}x{h} {spp} spp, {len(scene.triangles) + len(scene.spheres)} prims, "
+        print(f"{name} {builder}: {w}x{h} {spp} spp, {len(scene.triangles) + len(scene.spheres)} prims, {ctx.kernel_name()}, "
               f"{stats.rays} rays: {'bit-identical, counters equal' if same else 'MISMATCH'} (oracle {dt:.1f} s)", flush=True)
 print("FULL PARITY", "OK" if ok else "FAIL", flush=True)
 ctx.close()
