@@ -48,6 +48,9 @@ namespace {
 #ifndef RTGPU_WAVES_PER_EU
 #define RTGPU_WAVES_PER_EU (RTGPU_KBLOCK * RTGPU_BLOCKS_PER_CU / 256)
 #endif
+#ifndef RTGPU_WAVES_PER_EU_MAX  // experiments: a register budget the compiler may aim below without being held to it
+#define RTGPU_WAVES_PER_EU_MAX RTGPU_WAVES_PER_EU
+#endif
 constexpr int      kTriStep    = RTGPU_TRI_STEP;   // triangles a lane tests per leaf step (trees outside LDS)
 constexpr int      kBlock      = RTGPU_KBLOCK;
 #ifndef RTGPU_KBLOCK2
@@ -86,6 +89,21 @@ static_assert(kTinyEnd * 16 <= 65536, "MODE 7: every array within reach of a 16-
 // (the last plane's immediate ds_read offset, 5 * 16 * kWideCached, has to fit in 16 bits),
 // and the traversal stacks get the rest of the LDS, deeper entries going to global memory
 constexpr int      kWideCached = 768;
+constexpr int      kPathLdsWords = 6;  // slot-tree modes: words per lane kept in LDS behind the stacks (sum, throughput)
+// Launch shape of the slot-tree modes (11, 12): kSlotBlocksPerCU blocks of kBlockSlots threads per CU - one wave per SIMD and
+// block, so FIVE waves per SIMD where the 1024-thread block of the other modes gives four (two blocks of 640 threads never become
+// co-resident: the hardware spreads a ten-wave block 3 + 3 + 2 + 2 over the SIMDs, twice the same way).  The product kernels of
+// these modes live in 96 vector registers for it; their counting / profile variants do not and run four blocks per CU.
+#ifndef RTGPU_KBLOCK_SLOTS
+#define RTGPU_KBLOCK_SLOTS 256
+#endif
+#ifndef RTGPU_SLOT_BLOCKS_PER_CU
+#define RTGPU_SLOT_BLOCKS_PER_CU 5
+#endif
+constexpr int      kBlockSlots = RTGPU_KBLOCK_SLOTS;
+constexpr int      kSlotBlocksPerCU = RTGPU_SLOT_BLOCKS_PER_CU;
+constexpr int      kSlotWaves = kBlockSlots * kSlotBlocksPerCU / 256;               // waves per SIMD of the product kernels
+constexpr int      kLdsSlotBytes = 160 * 1024 / kSlotBlocksPerCU - 2048;           // LDS share of one such block
 constexpr int      kLdsMats    = 64;   // trees in memory: material tables up to this size are copied to LDS (2 KiB)
 constexpr unsigned kChunk      = 64;   // work items drawn per queue atomic (one 8x8 pixel block)
 constexpr float    kTMax       = 3.402823466e+38f;  // FLT_MAX: initial closest-hit distance
@@ -420,9 +438,11 @@ __device__ __forceinline__ void wave_tick(unsigned lane, unsigned long long &c) 
 // (The slot-exchange experiment of round 2 - modes 8-10 then, profiles/r02/experiments.txt H and J -
 // was a measured negative and is gone from the source.)
 template <int STATS, int REFILL, int MODE>
-__global__ __launch_bounds__(MODE == 8 ? kBlock2 : kBlock)
-__attribute__((amdgpu_waves_per_eu(MODE == 8 ? kBlock2 * RTGPU_BLOCKS_PER_CU / 256 : RTGPU_WAVES_PER_EU,
-                                   MODE == 8 ? kBlock2 * RTGPU_BLOCKS_PER_CU / 256 : RTGPU_WAVES_PER_EU)))
+__global__ __launch_bounds__(MODE == 8 ? kBlock2 : (MODE == 11 || MODE == 12) ? kBlockSlots : kBlock)
+__attribute__((amdgpu_waves_per_eu(MODE == 8 ? kBlock2 * RTGPU_BLOCKS_PER_CU / 256
+                                   : (MODE == 11 || MODE == 12) ? (STATS == 0 ? kSlotWaves : kSlotWaves - 1) : RTGPU_WAVES_PER_EU,
+                                   MODE == 8 ? kBlock2 * RTGPU_BLOCKS_PER_CU / 256
+                                   : (MODE == 11 || MODE == 12) ? (STATS == 0 ? kSlotWaves : kSlotWaves - 1) : RTGPU_WAVES_PER_EU_MAX)))
 void trace_kernel(const KParams P) {
   constexpr bool LDS_ONLY = MODE == 1 || MODE == 2 || MODE == 4 || MODE == 6 || MODE == 7 || MODE == 8 || MODE == 10 || MODE == 12,
                  SMALL = MODE == 2 || MODE == 7 || MODE == 8,
@@ -433,7 +453,7 @@ void trace_kernel(const KParams P) {
   // two bits of count and 28 of slot
   constexpr uint32_t CNT_SHIFT = SLOTS ? 28u : 27u, CNT_MASK = SLOTS ? 3u : 7u, FIRST_MASK = (1u << CNT_SHIFT) - 1u;
   constexpr int R = MODE == 8 ? 2 : 1;                  // rays a lane traverses in lock step
-  constexpr int BLOCK = MODE == 8 ? kBlock2 : kBlock;   // threads per block
+  constexpr int BLOCK = MODE == 8 ? kBlock2 : SLOTS ? kBlockSlots : kBlock;   // threads per block
   constexpr int STRIDE = BLOCK * R;                     // words between consecutive entries of one stack
 #ifdef RTGPU_NO_HIT_NORMAL  // experiments: shading fetches the triangle again
   constexpr bool KEEP_N = false;
@@ -452,7 +472,21 @@ void trace_kernel(const KParams P) {
   // LDS reads go through the texture addresser like global ones
   typedef float f4 __attribute__((ext_vector_type(4)));
   typedef __attribute__((address_space(3))) f4 lds_f4;
-  lds_f4 *const node_cache = (lds_f4 *)(smem + P.stack_lds * STRIDE);
+  // Slot-tree modes: the item's running sum and the path's throughput live in LDS behind the stacks (six words per lane, touched
+  // by the shading pass and when the item ends), not in registers: six of the registers that stood between these modes and a
+  // fifth wave per SIMD
+  constexpr bool SUM_LDS = SLOTS, DIET = SLOTS;
+  typedef __attribute__((address_space(3))) float lds_f32;
+  lds_f32 *const lds_sum = (lds_f32 *)(smem + P.stack_lds * STRIDE) + threadIdx.x;
+  lds_f32 *const lds_thr = lds_sum + 3 * BLOCK;
+  lds_f4 *const node_cache = (lds_f4 *)(smem + P.stack_lds * STRIDE + (SUM_LDS ? kPathLdsWords * BLOCK : 0));
+  auto thr_get = [&](const V3 &reg) __attribute__((always_inline)) {
+    return SUM_LDS ? mk(lds_thr[0], lds_thr[BLOCK], lds_thr[2 * BLOCK]) : reg;
+  };
+  auto thr_set = [&](V3 &reg, V3 v) __attribute__((always_inline)) {
+    if (SUM_LDS) { lds_thr[0] = v.x; lds_thr[BLOCK] = v.y; lds_thr[2 * BLOCK] = v.z; }
+    else reg = v;
+  };
   const unsigned tid = threadIdx.x;
   const unsigned lane = lane_id();
 
@@ -479,8 +513,12 @@ void trace_kernel(const KParams P) {
   typedef Stack<LDS_ONLY, STRIDE> StackT;
   struct Ray {
     bool done, alive, have_pixel, pixel_valid;
+    // the work item: pixel (DIET: x | y << 16 in px; both below 65536, checked at launch), its output slot, the sample being traced and the
+    // end of the item's samples, the chunk, the segment of the path, the primary hit of the frame's first sample.
+    // DIET (the slot-tree modes, which have to live in 96 registers for their fifth wave per SIMD): no sample_end (it follows
+    // from the chunk where it is needed) and no first_id (written to its output word when it is found); sum and thr in LDS.
     uint32_t px, py, out_index, sample, sample_end, chunk, bounce, first_id;
-    V3 sum, thr, ro, rd;
+    V3 sum, thr, ro, rd;  // (sum: in LDS for the slot-tree modes, SUM_LDS below)
     Rng rng;
     V3 new_dir;  // unnormalised direction of the segment about to start
     f2 inv_xy, inv_zx, inv_yz, noi_xy, noi_zx, noi_yz;
@@ -637,7 +675,19 @@ void trace_kernel(const KParams P) {
       V3 L = mk(0.f, 0.f, 0.f);
       bool path_end = false;
       const uint32_t hit_slot = S.hit_ref & FIRST_MASK;
+      // the primary hit of the frame's first sample goes straight to its output word (once per pixel)
+      auto write_first_id = [&](uint32_t id) __attribute__((always_inline)) {
+        if (S.bounce == 0 && S.sample == 0) {
+          if (DIET) {
+            KArgs K = kargs();
+            if (K->prim_id) K->prim_id[S.out_index] = id;
+          } else {
+            S.first_id = id;
+          }
+        }
+      };
       if (S.hit_ref == kDone) {
+        if (DIET) write_first_id(RTGPU_NO_HIT);
         float t = 0.5f * (S.rd.y + 1.0f);
         float a = 1.0f - t;
         V3 sb = sky_b_h, stp = sky_t_h;
@@ -647,7 +697,7 @@ void trace_kernel(const KParams P) {
           stp = mk(K->sky_top[0], K->sky_top[1], K->sky_top[2]);
         }
         V3 sky = mk(sb.x * a + stp.x * t, sb.y * a + stp.y * t, sb.z * a + stp.z * t);
-        L = S.thr * sky;
+        L = thr_get(S.thr) * sky;
         path_end = true;
       } else {
         V3 p = S.ro + S.rd * S.tbest;
@@ -692,7 +742,7 @@ void trace_kernel(const KParams P) {
             prim = S.hit_prim;
           }
         }
-        if (S.bounce == 0 && S.sample == 0) S.first_id = prim;
+        write_first_id(prim);
         float dn = dot(S.rd, n);
         bool front = dn < 0.0f;
         if (!front) n = neg(n);
@@ -719,7 +769,7 @@ void trace_kernel(const KParams P) {
           if (param > 0.0f) sd = sd + ruv * param;
           absorbed = !(dot(sd, n) > 0.0f);
         } else if (mtype == RTGPU_MAT_EMISSIVE) {
-          L = S.thr * (albedo * param);  // a light ends the path with its radiance, from either face
+          L = thr_get(S.thr) * (albedo * param);  // a light ends the path with its radiance, from either face
           sd = n;
           absorbed = true;
         } else {
@@ -746,7 +796,7 @@ void trace_kernel(const KParams P) {
         if (absorbed) {
           path_end = true;
         } else {
-          S.thr = S.thr * albedo;
+          thr_set(S.thr, thr_get(S.thr) * albedo);
           S.ro = p;
           S.new_dir = sd;  // normalised in (3), together with fresh camera rays
           S.bounce++;
@@ -754,7 +804,8 @@ void trace_kernel(const KParams P) {
         }
       }
       if (path_end) {
-        S.sum = S.sum + L;
+        if (SUM_LDS) { lds_sum[0] = lds_sum[0] + L.x; lds_sum[BLOCK] = lds_sum[BLOCK] + L.y; lds_sum[2 * BLOCK] = lds_sum[2 * BLOCK] + L.z; }
+        else S.sum = S.sum + L;
         S.sample++;
         S.alive = false;
       }
@@ -762,21 +813,29 @@ void trace_kernel(const KParams P) {
 
     SECTION_END(c_shade);
     // ---- (2) lanes without a path in flight: next sample, or next pixel ---------
-    bool need_pixel = !S.alive && !S.done && (!S.have_pixel || S.sample >= S.sample_end);
+    // last sample of the item + 1: the end of its chunk, or of the frame (an out-of-image pixel starts there)
+    auto sample_end_of = [&](const Ray &S_) __attribute__((always_inline)) {
+      if (!DIET) return S_.sample_end;
+      KArgs K = kargs();
+      const uint32_t e = (S_.chunk + 1u) * K->chunk_samples;
+      return e < K->spp ? e : K->spp;
+    };
+    bool need_pixel = !S.alive && !S.done && (!S.have_pixel || S.sample >= sample_end_of(S));
     if (need_pixel && S.have_pixel) {
       if (S.pixel_valid) {
         KArgs K = kargs();
+        const V3 sum = SUM_LDS ? mk(lds_sum[0], lds_sum[BLOCK], lds_sum[2 * BLOCK]) : S.sum;
         if (K->n_chunks > 1u) {
-          K->planes[(size_t)S.chunk * K->plane_stride + S.out_index] = make_float4(S.sum.x, S.sum.y, S.sum.z, 0.0f);
+          K->planes[(size_t)S.chunk * K->plane_stride + S.out_index] = make_float4(sum.x, sum.y, sum.z, 0.0f);
         } else {
-          float4 o = make_float4(S.sum.x, S.sum.y, S.sum.z, (float)K->spp);
+          float4 o = make_float4(sum.x, sum.y, sum.z, (float)K->spp);
           if (K->flags & RTGPU_FLAG_ACCUMULATE) {
             float4 in = K->accum[S.out_index];
             o.x = in.x + o.x; o.y = in.y + o.y; o.z = in.z + o.z; o.w = in.w + o.w;
           }
           K->accum[S.out_index] = o;
         }
-        if (K->prim_id && S.chunk == 0u) K->prim_id[S.out_index] = S.first_id;
+        if (!DIET && K->prim_id && S.chunk == 0u) K->prim_id[S.out_index] = S.first_id;
       }
       S.have_pixel = false;
     }
@@ -867,23 +926,25 @@ void trace_kernel(const KParams P) {
       const unsigned avail = pool_end - pool_next;  // wave-uniform, >= 1
       if (need_pixel && rank < avail) {
         const uint32_t within = (pool_next + rank) & 63u, wx = within & 7u, wy = within >> 3;
-        S.px = g_px + wx;
-        S.py = g_py + wy;
-        S.pixel_valid = S.px < P.width && S.py < P.height;
+        const uint32_t px = g_px + wx, py = g_py + wy;
+        S.px = DIET ? px | (py << 16) : px;
+        S.py = py;
+        S.pixel_valid = px < P.width && py < P.height;
         S.out_index = g_out + __umul24(wy, g_row) + wx;  // both below 2^24 (width <= 65536): v_mad_u32_u24 is full rate
         S.chunk = g_chunk;
         S.have_pixel = true;
         S.sample = S.pixel_valid ? g_sample : g_sample_end;  // out-of-image pixel: nothing to trace
         S.sample_end = g_sample_end;
-        S.sum = mk(0.f, 0.f, 0.f);
         S.first_id = RTGPU_NO_HIT;
+        if (SUM_LDS) { lds_sum[0] = 0.f; lds_sum[BLOCK] = 0.f; lds_sum[2 * BLOCK] = 0.f; }
+        else S.sum = mk(0.f, 0.f, 0.f);
         need_pixel = false;
       }
       pool_next += cnt < avail ? cnt : avail;
       need_mask = __ballot(need_pixel);
     }
     SECTION_END(c_item);
-    if (!S.alive && !S.done && S.have_pixel && S.sample < S.sample_end) {
+    if (!S.alive && !S.done && S.have_pixel && S.sample < sample_end_of(S)) {
       // ---- camera ray (row a1) ----
       if (STATS == 2) wave_tick(lane, w_gen);
       KArgs K = kargs();
@@ -896,10 +957,11 @@ void trace_kernel(const KParams P) {
         inv_w = K->inv_w; inv_h = K->inv_h; lens_radius = K->lens_radius; sample_offset = K->sample_offset; width = K->width;
       }
       // (the pixel's half of the key kept in a register per work item measured 0.8 % SLOWER on C2: a register more, a hash less)
-      S.rng.start(pcg((sample_offset + S.sample) ^ pcg((__umul24(S.py, width) + S.px) ^ seed_hash)));
+      const uint32_t px = DIET ? S.px & 0xFFFFu : S.px, py = DIET ? S.px >> 16 : S.py;
+      S.rng.start(pcg((sample_offset + S.sample) ^ pcg((__umul24(py, width) + px) ^ seed_hash)));
       float jx = S.rng.u01(), jy = S.rng.u01();
-      float sx = ((float)S.px + jx) * inv_w;
-      float sy = ((float)S.py + jy) * inv_h;
+      float sx = ((float)px + jx) * inv_w;
+      float sy = ((float)py + jy) * inv_h;
       V3 dir = ((cam_ll + cam_hor * sx) + cam_ver * sy) - cam_o;
       S.ro = cam_o;
       if (lens_radius > 0.0f) {
@@ -917,7 +979,7 @@ void trace_kernel(const KParams P) {
         dir = dir - off;
       }
       S.new_dir = dir;  // normalised in (3)
-      S.thr = mk(1.f, 1.f, 1.f);
+      thr_set(S.thr, mk(1.f, 1.f, 1.f));
       S.bounce = 0;
       S.alive = true;
       n_paths++;
@@ -1601,6 +1663,7 @@ struct rtgpu_ctx {
   float4 *d_planes = nullptr;   // chunk planes (grow-only, zero-filled when (re)allocated)
   size_t planes_bytes = 0;
   size_t ovf_threads = 0;
+  uint64_t last_waves = 0;      // waves of the last trace launch (rtgpu_debug_wave_times)
   // grow-only staging for the host-pointer entry points
   void *d_accum = nullptr;  size_t d_accum_bytes = 0;
   void *d_ids = nullptr;    size_t d_ids_bytes = 0;
@@ -1796,8 +1859,11 @@ extern "C" int rtgpu_create(rtgpu_ctx **out, int device_index) {
           return 2;
         }
   ctx->blocks_per_cu[0] = ctx->blocks_per_cu[1] = kBlocksPerCU;
-  ctx->ovf_threads = (size_t)ctx->num_cus * kBlocksPerCU * kBlock;
-  if ((e = hipMalloc((void **)&ctx->d_wave_times, (size_t)ctx->num_cus * kBlocksPerCU * (kBlock / 64) * 4 * 8)) != hipSuccess) {
+  // (threads per CU: the larger of the two launch shapes)
+  const size_t cu_threads = (size_t)kBlocksPerCU * kBlock > (size_t)kSlotBlocksPerCU * kBlockSlots ? (size_t)kBlocksPerCU * kBlock
+                                                                                                 : (size_t)kSlotBlocksPerCU * kBlockSlots;
+  ctx->ovf_threads = (size_t)ctx->num_cus * cu_threads;
+  if ((e = hipMalloc((void **)&ctx->d_wave_times, (size_t)ctx->num_cus * (cu_threads / 64) * 4 * 8)) != hipSuccess) {
     rtgpu::set_global_error(std::string("rtgpu_create: ") + hipGetErrorString(e));
     rtgpu_destroy(ctx);
     return 2;
@@ -2245,7 +2311,31 @@ int launch_frame(rtgpu_ctx *ctx, const rtgpu_camera *cam, const rtgpu_settings *
   const uint32_t need4 = ctx->host.max_stack4 + 4u;  // + sentinel + the three unconditional stores above the top
   const uint32_t cap4 = ctx->stack_lds == kStackLds ? stack_fit_all : (uint32_t)ctx->stack_lds;
   const bool wide = ctx->d_nodes4 != nullptr && need4 <= (cap4 < stack_fit_all ? cap4 : stack_fit_all) + (uint32_t)kStackOvf;
-  P.nodes = (const float4 *)(wide ? ctx->d_nodes4 : ctx->d_nodes48 ? ctx->d_nodes48 : ctx->d_nodes);
+  // four-wide trees: the top kWideCached nodes in LDS, the stack in what is left, deeper entries
+  // in the overflow buffer (MODE 5).  The bound need4 is a worst case few rays come near, and the
+  // vector memory pipeline is what these scenes wait for (DESIGN.md §8).  Not for the entry point
+  // that may not use the context's overflow buffer, nor with RTGPU_WIDE_CACHE=0 (experiments).
+  const bool wide_cache = wide && ctx->wide_cache && sc.may_allocate && kBlocksPerCU == 1;
+  // The slot tree (modes 11, 12) in preference to the four-wide nodes it is made from, when this tree has one.  Made here, by
+  // the first frame after an upload / build / refit; the entry point that may not allocate uses it only if it exists already -
+  // and only if the whole stack fits the smaller LDS share of these modes' blocks (it has no overflow stack).
+  const uint32_t slot_stack_fit = (uint32_t)((kLdsSlotBytes - kPathLdsWords * kBlockSlots * (int)sizeof(uint32_t)) / (kBlockSlots * sizeof(uint32_t)));
+  bool slots = false;
+  if (wide && !wide_cache && kBlocksPerCU == 1) {
+    const bool want_slots = ctx->slot_tree >= 0 ? ctx->slot_tree != 0 : kSlotTreeDefault;
+    if (want_slots && ctx->slot_state == 0 && sc.may_allocate) {
+      if (rtgpu::build_slot_tree_device(ctx->d_nodes4, ctx->host.n_nodes4, ctx->d_tris, ctx->d_sphs, ctx->d_sph_meta, &ctx->slot,
+                                        &ctx->pool, (void *)stream, ctx->err))
+        return 2;
+      ctx->slot_state = ctx->slot.n_slots > 0 ? 1 : 2;
+    }
+    slots = want_slots && ctx->slot_state == 1;
+    if (slots && !sc.may_allocate && need4 > (cap4 < slot_stack_fit ? cap4 : slot_stack_fit)) slots = false;
+  }
+  const unsigned block_threads = slots ? (unsigned)kBlockSlots : (unsigned)kBlock;      // (MODE 8 picks its own below)
+  const size_t lds_budget = slots ? (size_t)kLdsSlotBytes : (size_t)kLdsBytes;
+  const size_t path_bytes = slots ? (size_t)kPathLdsWords * kBlockSlots * sizeof(uint32_t) : 0;  // sum and throughput per lane
+  P.nodes = (const float4 *)(slots ? ctx->slot.d_slots : wide ? ctx->d_nodes4 : ctx->d_nodes48 ? ctx->d_nodes48 : ctx->d_nodes);
   P.tris = (const float4 *)ctx->d_tris;
   P.sphs = (const float4 *)ctx->d_sphs;
   P.sph_meta = (const uint2 *)ctx->d_sph_meta;
@@ -2282,12 +2372,7 @@ int launch_frame(rtgpu_ctx *ctx, const rtgpu_camera *cam, const rtgpu_settings *
   uint32_t stack_lds = need < 8u ? 8u : need;
   const uint32_t cap = wide ? cap4 : (uint32_t)ctx->stack_lds;  // kStackLds (the whole LDS for four-wide nodes), or RTGPU_STACK_LDS
   if (stack_lds > cap) stack_lds = cap;
-  uint32_t stack_fit = (uint32_t)(kLdsBytes / (kBlock * sizeof(uint32_t)));      // entries the block's LDS share holds
-  // four-wide trees: the top kWideCached nodes in LDS, the stack in what is left, deeper entries
-  // in the overflow buffer (MODE 5).  The bound need4 is a worst case few rays come near, and the
-  // vector memory pipeline is what these scenes wait for (DESIGN.md §8).  Not for the entry point
-  // that may not use the context's overflow buffer, nor with RTGPU_WIDE_CACHE=0 (experiments).
-  const bool wide_cache = wide && ctx->wide_cache && sc.may_allocate && kBlocksPerCU == 1;
+  uint32_t stack_fit = (uint32_t)((lds_budget - path_bytes) / (block_threads * sizeof(uint32_t)));      // entries the block's LDS share holds
   if (wide_cache) stack_fit = (uint32_t)((kLdsBytes - kWideCached * (int)sizeof(rtgpu_node4)) / (kBlock * sizeof(uint32_t)));
   if (stack_lds > stack_fit) stack_lds = stack_fit;
   P.stack_lds = stack_lds;
@@ -2298,8 +2383,8 @@ int launch_frame(rtgpu_ctx *ctx, const rtgpu_camera *cam, const rtgpu_settings *
   }
   // small scenes: the whole tree in LDS with planes kSmallNodes apart (MODE 2); larger
   // trees are fetched through L1 (a partial cache measured no gain)
-  const size_t stack_bytes = (size_t)stack_lds * kBlock * sizeof(uint32_t);
-  size_t lds_bytes = stack_bytes;
+  const size_t stack_bytes = (size_t)stack_lds * block_threads * sizeof(uint32_t);
+  size_t lds_bytes = stack_bytes + path_bytes;
   int mode = P.stack_lds_only ? 1 : 0;
   P.n_cached = 0;
   if (mode == 1 && !ctx->no_node_cache && !wide && !ctx->d_nodes48 && ctx->host.n_nodes <= (uint64_t)kSmallNodes &&
@@ -2333,21 +2418,7 @@ int launch_frame(rtgpu_ctx *ctx, const rtgpu_camera *cam, const rtgpu_settings *
     if (mode == 2 || mode >= 7) { ctx->err = "internal: packed nodes on a tree that fits the LDS cache"; return 2; }
     mode += wide ? 5 : 3;
   }
-  // The slot tree (modes 11, 12) in preference to the four-wide nodes it is made from, when this tree has one.  Made here, by
-  // the first frame after an upload / build / refit; the entry point that may not allocate uses it only if it exists already.
-  if ((mode == 5 || mode == 6) && !wide_cache) {
-    const bool want_slots = ctx->slot_tree >= 0 ? ctx->slot_tree != 0 : kSlotTreeDefault;
-    if (want_slots && ctx->slot_state == 0 && sc.may_allocate) {
-      if (rtgpu::build_slot_tree_device(ctx->d_nodes4, ctx->host.n_nodes4, ctx->d_tris, ctx->d_sphs, ctx->d_sph_meta, &ctx->slot,
-                                        &ctx->pool, (void *)stream, ctx->err))
-        return 2;
-      ctx->slot_state = ctx->slot.n_slots > 0 ? 1 : 2;
-    }
-    if (want_slots && ctx->slot_state == 1) {
-      P.nodes = (const float4 *)ctx->slot.d_slots;
-      mode += 6;  // 5 -> 11, 6 -> 12
-    }
-  }
+  if (slots) mode += 6;  // 5 -> 11, 6 -> 12
   // Trees far larger than the caches: the four-wide nodes in 128-byte slots (modes 9, 10).  The padded copy is made here, by
   // the first frame after an upload / build / refit; the entry point that may not allocate uses it only if it exists already.
   if ((mode == 5 || mode == 6) && !wide_cache) {
@@ -2380,12 +2451,12 @@ int launch_frame(rtgpu_ctx *ctx, const rtgpu_camera *cam, const rtgpu_settings *
   if (mode != 2 && mode != 7 && mode != 8 && !ctx->no_mats_cache && ctx->host.n_materials > 0 &&
       ctx->host.n_materials <= (uint64_t)kLdsMats && kBlocksPerCU == 1) {
     const size_t mb = (size_t)ctx->host.n_materials * sizeof(rtgpu_material);
-    if (lds_bytes + mb > (size_t)kLdsBytes && !P.stack_lds_only && sc.may_allocate && P.stack_lds > 8u) {
-      // an overflow-capable stack gives up one LDS entry for the table
+    while (lds_bytes + mb > lds_budget && !P.stack_lds_only && sc.may_allocate && P.stack_lds > 8u) {
+      // an overflow-capable stack gives up LDS entries for the table (one where a block has 1024 threads, two where it has 256)
       P.stack_lds -= 1u;
-      lds_bytes -= (size_t)kBlock * sizeof(uint32_t);
+      lds_bytes -= (size_t)block_threads * sizeof(uint32_t);
     }
-    if (lds_bytes + mb <= (size_t)kLdsBytes) {
+    if (lds_bytes + mb <= lds_budget) {
       P.mats_cached = (uint32_t)ctx->host.n_materials;
       lds_bytes += mb;
     }
@@ -2395,16 +2466,19 @@ int launch_frame(rtgpu_ctx *ctx, const rtgpu_camera *cam, const rtgpu_settings *
   HIP_TRY(ctx, hipMemsetAsync(sc.counters, 0, kCounterBytes, stream));
   ctx->timed = false;
   if (n_items > 0) {
-    const unsigned block = mode == 8 ? (unsigned)kBlock2 : (unsigned)kBlock;
-    const uint64_t per_block = mode == 8 ? 2ull * kBlock2 : (uint64_t)kBlock;   // work items a block holds at a time
+    const int inst = (s->flags & RTGPU_FLAG_PROFILE) ? 2 : want_stats ? 1 : 0;
+    const unsigned block = mode == 8 ? (unsigned)kBlock2 : block_threads;
+    const uint64_t per_block = mode == 8 ? 2ull * kBlock2 : (uint64_t)block;   // work items a block holds at a time
     uint64_t want = (n_items + per_block - 1) / per_block;
-    uint64_t cap = (uint64_t)ctx->num_cus * (uint64_t)ctx->blocks_per_cu[want_stats ? 1 : 0];
+    // (slot-tree modes: five blocks of 256 threads per CU; their counting and profile variants need more registers: four)
+    const uint64_t per_cu = slots ? (uint64_t)(inst == 0 ? kSlotBlocksPerCU : kSlotBlocksPerCU - 1) : (uint64_t)ctx->blocks_per_cu[want_stats ? 1 : 0];
+    uint64_t cap = (uint64_t)ctx->num_cus * per_cu;
     unsigned grid = (unsigned)(want < cap ? want : cap);
-    if ((size_t)grid * kBlock > ctx->ovf_threads) { ctx->err = "internal: grid exceeds the overflow stack"; return 2; }
+    if ((size_t)grid * block > ctx->ovf_threads) { ctx->err = "internal: grid exceeds the overflow stack"; return 2; }
+    ctx->last_waves = (uint64_t)grid * (block / 64u);
     const Variant &var = kVariants[ctx->variant >= 0 ? ctx->variant : (mode == 2 || mode == 7 || mode == 8 ? kVariantSmallTree : kVariantLargeTree)];
     static_assert(RTGPU_NODE48_MIN_NODES > (unsigned)kSmallNodes, "a packed tree must not fit the LDS node cache");
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
-    const int inst = (s->flags & RTGPU_FLAG_PROFILE) ? 2 : want_stats ? 1 : 0;
     KernelFn fn = var.fn[inst][mode];
     std::snprintf(ctx->kernel_name, sizeof(ctx->kernel_name), "trace_kernel<%d,%d,%d>", inst, var.refill, mode);
     hipLaunchKernelGGL(fn, dim3(grid), dim3(block), lds_bytes, stream, P);
@@ -2518,7 +2592,7 @@ extern "C" int rtgpu_debug_slot_tree(rtgpu_ctx *ctx, uint32_t *out, uint64_t max
 // (4 u64 per wave).
 extern "C" int rtgpu_debug_wave_times(rtgpu_ctx *ctx, uint64_t *out, uint64_t max_waves, uint64_t *n_waves) {
   if (!ctx || !out || !n_waves) return 1;
-  uint64_t n = (uint64_t)ctx->num_cus * kBlocksPerCU * (kBlock / 64);
+  uint64_t n = ctx->last_waves ? ctx->last_waves : (uint64_t)ctx->num_cus * kBlocksPerCU * (kBlock / 64);
   if (n > max_waves) n = max_waves;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipDeviceSynchronize());

@@ -8,17 +8,18 @@ from util import assert_bit_equal
 
 pytestmark = pytest.mark.gpu
 
-# switch -> kernel mode expected on (S0: the whole scene fits LDS, a mesh whose tree lives in memory: its slot tree, or with
-# RTGPU_SLOT_TREE=0 the four-wide nodes the slot tree is made from)
+# switch -> kernel mode expected on (S0: the whole scene fits LDS, a mesh whose tree lives in memory: its slot tree - mode 11: the
+# blocks of the slot-tree modes hold 24 stack entries per lane in LDS and this tree's bound is 29; mode 12 is covered in
+# tests/test_gpu_slot_tree.py - or with RTGPU_SLOT_TREE=0 the four-wide nodes the slot tree is made from)
 CASES = [
-    ({}, ((7, 8), 12)),                                             # (7 or 8: whichever the build makes the default)
-    ({"RTGPU_NO_TINY": "1"}, (2, 12)),                              # the tree in LDS, spheres behind it
-    ({"RTGPU_NO_SPHERE_CACHE": "1"}, (2, 12)),                      # the tree in LDS, spheres through L1
-    ({"RTGPU_RAYS2": "1"}, (8, 12)),                                # two rays per lane in lock step (scenes in LDS)
-    ({"RTGPU_RAYS2": "0"}, (7, 12)),                                # one ray per lane
-    ({"RTGPU_STACK_LDS": "14"}, (7, 11)),                           # the deeper stack entries in memory
-    ({"RTGPU_REFILL": "0"}, (7, 12)),                               # plain while-while traversal rounds
-    ({"RTGPU_NO_MATS_CACHE": "1"}, (7, 12)),                        # trees in memory: materials through L1, not LDS
+    ({}, ((7, 8), 11)),                                             # (7 or 8: whichever the build makes the default)
+    ({"RTGPU_NO_TINY": "1"}, (2, 11)),                              # the tree in LDS, spheres behind it
+    ({"RTGPU_NO_SPHERE_CACHE": "1"}, (2, 11)),                      # the tree in LDS, spheres through L1
+    ({"RTGPU_RAYS2": "1"}, (8, 11)),                                # two rays per lane in lock step (scenes in LDS)
+    ({"RTGPU_RAYS2": "0"}, (7, 11)),                                # one ray per lane
+    ({"RTGPU_STACK_LDS": "9"}, (0, 11)),                            # nine stack entries in LDS, the rest in memory: S0's tree too
+    ({"RTGPU_REFILL": "0"}, (7, 11)),                               # plain while-while traversal rounds
+    ({"RTGPU_NO_MATS_CACHE": "1"}, (7, 11)),                        # trees in memory: materials through L1, not LDS
 ]
 # the same over the four-wide nodes: their boxes are tighter than the slot tree's halves, so the counters of node visits and
 # triangle tests are smaller, and equal among these; frame and ids are the slot tree's
