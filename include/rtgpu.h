@@ -298,9 +298,10 @@ int  rtgpu_render_device(rtgpu_ctx *ctx, const rtgpu_camera *cam, const rtgpu_se
  *     rtgpu_render_device);
  *   - no RTGPU_FLAG_PROFILE; counters of RTGPU_FLAG_STATS are read with rtgpu_profile_counters.
  * A tree that lives in memory is traversed through its slot tree (rtgpu_format.h), which rtgpu_render_device
- * makes on the first frame after an upload, build or refit and this call cannot: before such a frame it
- * traverses the four-wide nodes the slot tree is made from - the same hits, 0.2 % fewer node visits in the
- * counters, a few per cent more time.
+ * makes on the first frame after an upload, build or refit and this call cannot; and the kernels of the slot
+ * tree keep 24 stack entries per lane in LDS, the rest in the overflow stack this call does not have.  Before
+ * such a frame, or for a tree whose stack bound is above 24, it traverses the four-wide nodes the slot tree is
+ * made from - the same hits, 0.2 % fewer node visits in the counters, 4-15 % more time.
  * All contexts of a process on one GPU share that GPU's array and it keeps the last call's
  * contents (the call clears what has to start at zero): two calls that OVERLAP on one GPU -
  * two contexts, or one context from two threads - race.  Calls of one context on different
