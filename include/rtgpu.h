@@ -125,7 +125,8 @@ typedef struct rtgpu_settings {
                             * kernel; the value is part of the arithmetic contract.
                             * rtgpu_default_settings: 2 below 16 spp, 4 up to 256
                             * spp, else ceil(spp / 64); n chunks > 1 cost n x 16 B per pixel
-                            * of context memory (the chunk planes) */
+                            * of context memory (the chunk planes), 65 x 16 B at most: a
+                            * frame of more than 64 chunks is traced in rounds of 64 */
 } rtgpu_settings;
 
 typedef struct rtgpu_stats {
@@ -290,7 +291,7 @@ int  rtgpu_render_device(rtgpu_ctx *ctx, const rtgpu_camera *cam, const rtgpu_se
  * of context buffers that grow on demand.  No hipMalloc, hipFree or other allocating routine
  * is reached from this call; it is asynchronous on `stream` like rtgpu_render_device.
  * Limits, each answered with a non-zero return and a message instead of an allocation:
- *   - chunk planes: ceil(spp / chunk_samples) x output pixels x 16 B must fit
+ *   - chunk planes: min(ceil(spp / chunk_samples), 65) x output pixels x 16 B must fit
  *     rtgpu_static_scratch_bytes() (64 MiB: 1920x1080 in up to 2 chunks, 1280x720 in up to 4;
  *     one chunk - chunk_samples >= spp - needs no planes and fits any frame);
  *   - the traversal stack of the uploaded tree must fit LDS (true for every tree up to depth

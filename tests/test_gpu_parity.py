@@ -313,9 +313,11 @@ def test_thin_lens_and_settings(ra, oracle, gpu_ctx):
     assert sa == sb
 
 
-@pytest.mark.parametrize("spp,chunk", [(16, 4), (16, 1), (7, 3), (5, 8), (33, 2)])
+@pytest.mark.parametrize("spp,chunk", [(16, 4), (16, 1), (7, 3), (5, 8), (33, 2), (64, 1), (65, 1), (70, 1), (129, 1), (200, 3)])
 def test_chunked_frame_sum(ra, oracle, gpu_ctx, spp, chunk):
-    """Work items are (pixel, chunk of samples); chunk planes are combined in order."""
+    """Work items are (pixel, chunk of samples); chunk planes are combined in order.  A frame of more than 64 chunks is traced
+    in rounds of 64 with the running sum in a plane of its own: 65 chunks (a last round of one), 70, 129 (two full rounds and
+    one chunk), 67; 64 is still one round."""
     scene, cam = ra.Scene.builtin(0, aspect=200 / 120)
     st = ra.default_settings(200, 120, spp=spp, max_depth=8, chunk_samples=chunk, tile_size=16)
     (a, ia, sa), (b, ib, sb) = render_both(ra, oracle, gpu_ctx, scene, cam, st)
@@ -327,6 +329,31 @@ def test_chunked_frame_sum(ra, oracle, gpu_ctx, spp, chunk):
     a2, _, _ = gpu_ctx.render(cam, st, accum=a.copy())
     b2, _, _ = oracle.render(gpu_ctx.flat_scene().c, cam, st, accum=b.copy(), threads=16)
     assert_bit_equal(a2, b2, "accumulate")
+
+
+def test_rounds_of_chunks_on_every_rank(ra, oracle, gpu_ctx):
+    """Compact per-rank frames of 70 chunks (two rounds): together they are the one-GPU frame, which is the oracle's."""
+    w, h, ts = 96, 64, 16
+    scene, cam = ra.Scene.builtin(0, aspect=w / h)
+    gpu_ctx.upload(scene)
+    st = ra.default_settings(w, h, spp=70, max_depth=6, chunk_samples=1, tile_size=ts, flags=ra.FLAG_STATS)
+    full, full_ids, full_stats = gpu_ctx.render(cam, st)
+    b, ib, sb = oracle.render(gpu_ctx.flat_scene().c, cam, st, threads=16)
+    assert_bit_equal(full, b, "70 chunks")
+    assert np.array_equal(full_ids, ib) and full_stats.as_dict() == sb
+    from rt_amd import dist as rdist
+    world = 3
+    parts, rays = [], 0
+    n = rdist.padded_pixels(w, h, ts, world)
+    for r in range(world):
+        st_r = ra.default_settings(w, h, spp=70, max_depth=6, chunk_samples=1, tile_size=ts, rank=r, world_size=world,
+                                   flags=ra.FLAG_COMPACT | ra.FLAG_STATS)
+        a, _, s_r = gpu_ctx.render(cam, st_r)
+        rays += s_r.rays
+        pa = np.zeros((n, 4), np.float32); pa[:len(a)] = a
+        parts.append(pa)
+    assert rays == full_stats.rays
+    assert_bit_equal(rdist.untile_host(np.concatenate(parts), w, h, ts, world), full, "three ranks, two rounds each")
 
 
 def test_default_chunk_rule_at_high_spp(ra, oracle, gpu_ctx):

@@ -72,6 +72,19 @@ def test_frames_through_the_slot_tree(ra, oracle, gpu_ctx, builder):
     assert sb["sphere_tests"] > 0 and sb["tri_tests"] > 0 and len(np.unique(ia)) > 200
 
 
+def test_rounds_of_chunks_over_the_slot_tree(ra, oracle, gpu_ctx):
+    """132 spp in chunks of two = 66 chunks = two rounds: the slot-tree kernels derive an item's last sample from its chunk and the
+    round's first chunk, and write the first sample's primary hit in the first round only."""
+    scene, cam = ra.Scene.builtin(1, param=5, aspect=1.5)
+    st = ra.default_settings(60, 40, spp=132, max_depth=6, chunk_samples=2, seed=4, flags=ra.FLAG_STATS)
+    gpu_ctx.upload(scene)
+    a, ia, sa = gpu_ctx.render(cam, st)
+    assert _mode(gpu_ctx) == 11
+    b, ib, sb = oracle.render(gpu_ctx.flat_scene().c, cam, st, threads=8)
+    assert_bit_equal(a, b, "66 chunks over the slot tree")
+    assert np.array_equal(ia, ib) and sa.as_dict() == sb
+
+
 def test_shallow_tree_keeps_its_whole_stack_in_lds(ra, oracle, gpu_ctx):
     """A tree whose stack bound fits the LDS share of a slot-tree block runs mode 12 (no overflow stack): 2304 spheres on a grid
     (four-wide stack bound 17 + 4), every material kind, counters included; frames with and without statistics agree (their kernels
