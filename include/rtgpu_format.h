@@ -83,7 +83,8 @@ typedef struct rtgpu_node4 {
 
 /* Slot tree: the four-wide tree AND its primitives as one array of 64-byte slots (16 words), made on the
  * device from the four-wide nodes and the leaf-ordered arrays (rt_amd/csrc/slot_tree.hip; restated in
- * oracle/rt_oracle.c) and traversed in preference to them by the trace loop and the oracle.  On trees in
+ * oracle/rt_oracle.c; rewritten in place after a refit, whose topology and therefore slot numbering stay)
+ * and traversed in preference to them by the trace loop and the oracle.  On trees in
  * memory the trace loop's time follows the 16-byte loads a lane issues and the 128-byte lines they touch
  * (DESIGN.md §5.2): a node is four loads here instead of six, no record lies across a line, and the
  * children of a node are adjacent.

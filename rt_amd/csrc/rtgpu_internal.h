@@ -44,9 +44,19 @@ struct SlotTreeDevice {
   void *d_slots = nullptr;
   size_t cap_bytes = 0;
   uint64_t n_slots = 0;
+  // the layout, kept for refreshes after refits: family base and slot of every four-wide node, slot of every primitive
+  uint32_t *d_base = nullptr, *d_slot_of = nullptr, *d_tri_slot = nullptr, *d_sph_slot = nullptr;
+  size_t cap_base = 0, cap_slot_of = 0, cap_tri_slot = 0, cap_sph_slot = 0;
+  bool layout_valid = false;
+  uint64_t layout_n4 = 0, layout_tris = 0, layout_sphs = 0, layout_slots = 0;
 };
-int  build_slot_tree_device(const void *d_nodes4, uint64_t n4, const void *d_tris, const void *d_sphs, const void *d_sph_meta,
-                            SlotTreeDevice *out, DevPool *pool, void *stream /* hipStream_t */, std::string &err);
+int  build_slot_tree_device(const void *d_nodes4, uint64_t n4, const void *d_tris, uint64_t n_tris, const void *d_sphs,
+                            const void *d_sph_meta, uint64_t n_sphs, SlotTreeDevice *out, DevPool *pool,
+                            void *stream /* hipStream_t */, std::string &err);
+// the same tree after a refit (same topology, same counts): the slots rewritten in place, no scan
+int  refresh_slot_tree_device(const void *d_nodes4, const void *d_tris, const void *d_sphs, const void *d_sph_meta,
+                              SlotTreeDevice *out, DevPool *pool, void *stream /* hipStream_t */, std::string &err);
+void free_slot_tree_device(SlotTreeDevice *out);
 
 // lbvh_build.hip: the same flattened scene built on the GPU (device arrays, caller frees with free_lbvh)
 struct LbvhDevice {

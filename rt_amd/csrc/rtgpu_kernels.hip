@@ -1640,7 +1640,8 @@ struct rtgpu_ctx {
   bool pad_valid = false;
   int pad_nodes4 = -1;          // RTGPU_NODE4_PAD=0/1 forces the choice; -1: by the size of the tree (kPadMinBytes)
   // the slot tree (rtgpu_format.h; modes 11, 12): made from d_nodes4 and the primitive arrays by the first frame after an
-  // upload, build or refit.  slot_state: 0 not made yet, 1 valid, 2 this tree has no slot form (the four-wide nodes are used)
+  // upload, build or refit.  slot_state: 0 not made yet, 1 valid, 2 this tree has no slot form (the four-wide nodes are used),
+  // 3 made for this topology but the geometry has been refitted since: refreshed in place by the next frame
   rtgpu::SlotTreeDevice slot;
   int slot_state = 0;
   int slot_tree = -1;           // RTGPU_SLOT_TREE=0/1 forces the choice; -1: kSlotTreeDefault
@@ -1753,6 +1754,7 @@ void free_scene_device(rtgpu_ctx *ctx) {
   ctx->d_nodes4_src = nullptr;
   ctx->pad_valid = false;  // (the padded copy's memory is kept for the next scene)
   ctx->slot_state = 0;     // (and the slot tree's)
+  ctx->slot.layout_valid = false;  // (its layout belonged to the scene that goes)
   rtgpu::free_flat_scene(&ctx->host);
   ctx->have_scene = false;
   ctx->host_stale = false;
@@ -1901,7 +1903,7 @@ extern "C" void rtgpu_destroy(rtgpu_ctx *ctx) {
   (void)hipFree(ctx->d_wave_times);
   (void)hipFree(ctx->d_planes);
   (void)hipFree(ctx->d_nodes4_pad);
-  (void)hipFree(ctx->slot.d_slots);
+  rtgpu::free_slot_tree_device(&ctx->slot);
   (void)hipFree(ctx->d_accum);
   (void)hipFree(ctx->d_ids);
   (void)hipFree(ctx->d_res_accum);
@@ -2145,7 +2147,7 @@ extern "C" int rtgpu_refit(rtgpu_ctx *ctx, const rtgpu_scene_desc *scene) {
   h.build_ms = ms;
   ctx->res_valid = false;  // new geometry: rtgpu_render_resolved starts its sum again (include/rtgpu.h)
   ctx->pad_valid = false;  // ... and the padded copy of the four-wide nodes is remade by the next frame
-  ctx->slot_state = 0;     // ... and the slot tree
+  ctx->slot_state = ctx->slot.layout_valid ? 3 : 0;  // ... and the slot tree refreshed (its layout follows the topology, which stays)
   return 0;
 }
 
@@ -2185,7 +2187,7 @@ extern "C" int rtgpu_refit_device(rtgpu_ctx *ctx, const void *d_spheres, uint64_
   h.build_ms = ms;
   ctx->res_valid = false;  // new geometry: rtgpu_render_resolved starts its sum again (include/rtgpu.h)
   ctx->pad_valid = false;  // ... and the padded copy of the four-wide nodes is remade by the next frame
-  ctx->slot_state = 0;     // ... and the slot tree
+  ctx->slot_state = ctx->slot.layout_valid ? 3 : 0;  // ... and the slot tree refreshed (its layout follows the topology, which stays)
   return 0;
 }
 
@@ -2340,9 +2342,14 @@ int launch_frame(rtgpu_ctx *ctx, const rtgpu_camera *cam, const rtgpu_settings *
   bool slots = false;
   if (wide && !wide_cache && kBlocksPerCU == 1) {
     const bool want_slots = ctx->slot_tree >= 0 ? ctx->slot_tree != 0 : kSlotTreeDefault;
+    if (want_slots && ctx->slot_state == 3 && sc.may_allocate) {
+      if (rtgpu::refresh_slot_tree_device(ctx->d_nodes4, ctx->d_tris, ctx->d_sphs, ctx->d_sph_meta, &ctx->slot, &ctx->pool, (void *)stream, ctx->err))
+        return 2;
+      ctx->slot_state = ctx->slot.n_slots > 0 ? 1 : 2;
+    }
     if (want_slots && ctx->slot_state == 0 && sc.may_allocate) {
-      if (rtgpu::build_slot_tree_device(ctx->d_nodes4, ctx->host.n_nodes4, ctx->d_tris, ctx->d_sphs, ctx->d_sph_meta, &ctx->slot,
-                                        &ctx->pool, (void *)stream, ctx->err))
+      if (rtgpu::build_slot_tree_device(ctx->d_nodes4, ctx->host.n_nodes4, ctx->d_tris, ctx->host.n_tris, ctx->d_sphs, ctx->d_sph_meta,
+                                        ctx->host.n_spheres, &ctx->slot, &ctx->pool, (void *)stream, ctx->err))
         return 2;
       ctx->slot_state = ctx->slot.n_slots > 0 ? 1 : 2;
     }
@@ -2616,9 +2623,14 @@ extern "C" int rtgpu_debug_slot_tree(rtgpu_ctx *ctx, uint32_t *out, uint64_t max
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipDeviceSynchronize());
   if (!ctx->d_nodes4) return 0;
+  if (ctx->slot_state == 3) {
+    if (rtgpu::refresh_slot_tree_device(ctx->d_nodes4, ctx->d_tris, ctx->d_sphs, ctx->d_sph_meta, &ctx->slot, &ctx->pool, nullptr, ctx->err))
+      return 2;
+    ctx->slot_state = ctx->slot.n_slots > 0 ? 1 : 2;
+  }
   if (ctx->slot_state == 0) {
-    if (rtgpu::build_slot_tree_device(ctx->d_nodes4, ctx->host.n_nodes4, ctx->d_tris, ctx->d_sphs, ctx->d_sph_meta, &ctx->slot,
-                                      &ctx->pool, nullptr, ctx->err))
+    if (rtgpu::build_slot_tree_device(ctx->d_nodes4, ctx->host.n_nodes4, ctx->d_tris, ctx->host.n_tris, ctx->d_sphs, ctx->d_sph_meta,
+                                      ctx->host.n_spheres, &ctx->slot, &ctx->pool, nullptr, ctx->err))
       return 2;
     ctx->slot_state = ctx->slot.n_slots > 0 ? 1 : 2;
   }

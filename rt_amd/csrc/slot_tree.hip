@@ -5,6 +5,9 @@
 //      order of their parents, so a family is contiguous and every child lies after its parent;
 //   2. every inner child learns its slot from its parent;
 //   3. every node writes its own slot and copies the primitives of its leaf children into the family.
+// The layout (which slot every node and every primitive has) depends on the topology only: it is kept, and after a REFIT -
+// new boxes and primitives under the same tree - the slots are refreshed in place by kernels that need no scan and no
+// look at the tree's shape: one thread per node for the node slots, four per triangle for the triangle slots.
 // No reference counterpart (the reference has no BVH).
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_scan.hpp>
@@ -54,7 +57,7 @@ __global__ __launch_bounds__(256) void child_slots_kernel(const rtgpu_node4 *n4,
 
 __global__ __launch_bounds__(256) void write_slots_kernel(const rtgpu_node4 *n4, uint32_t n, const uint32_t *base, const uint32_t *slot_of,
                                                           const uint4 *tris, const uint4 *sphs, const uint2 *sph_meta,
-                                                          uint4 *slots, uint32_t *bad) {
+                                                          uint4 *slots, uint32_t *tri_slot, uint32_t *sph_slot, uint32_t *bad) {
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
     const rtgpu_node4 nd = n4[i];
     const uint32_t family = 1u + base[i];
@@ -71,11 +74,13 @@ __global__ __launch_bounds__(256) void write_slots_kernel(const rtgpu_node4 *n4,
         for (uint32_t j = 0; j < c.size; j++) {
           uint4 *p = slots + 4 * (size_t)(at + j);
           if (c.ref & RTGPU_REF_SPHERE) {
+            sph_slot[first + j] = at + j;
             const uint2 m = sph_meta[first + j];
             p[0] = sphs[first + j];
             p[1] = make_uint4(m.x, m.y, 0u, 0u);
             p[2] = p[3] = make_uint4(0u, 0u, 0u, 0u);
           } else {
+            tri_slot[first + j] = at + j;
             const uint4 *t = tris + 3 * (size_t)(first + j);
             p[0] = t[0]; p[1] = t[1]; p[2] = t[2];
             p[3] = make_uint4(0u, 0u, 0u, 0u);
@@ -87,6 +92,45 @@ __global__ __launch_bounds__(256) void write_slots_kernel(const rtgpu_node4 *n4,
   }
 }
 
+// ---- refresh after a refit: the same layout, new boxes and primitives ----
+__global__ __launch_bounds__(256) void refresh_node_slots_kernel(const rtgpu_node4 *n4, uint32_t n, const uint32_t *base, const uint32_t *slot_of,
+                                                                 uint4 *slots, uint32_t *bad) {
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+    uint32_t w[16];
+    if (!rtgpu::make_node_slot(n4[i], 1u + base[i], w)) { atomicOr(bad, 4u); continue; }
+    uint4 *dst = slots + 4 * (size_t)slot_of[i];
+    for (int q = 0; q < 4; q++) dst[q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+  }
+}
+// four threads per triangle: quarter q of the record to quarter q of its slot (the fourth quarter of a slot is zero)
+__global__ __launch_bounds__(256) void refresh_tri_slots_kernel(const uint4 *tris, uint64_t n_tris, const uint32_t *tri_slot, uint4 *slots) {
+  const uint64_t total = n_tris * 4;
+  for (uint64_t k = (uint64_t)blockIdx.x * 256u + threadIdx.x; k < total; k += (uint64_t)gridDim.x * 256u) {
+    const uint64_t t = k >> 2;
+    const uint32_t q = (uint32_t)k & 3u;
+    slots[4 * (size_t)tri_slot[t] + q] = q < 3u ? tris[3 * t + q] : make_uint4(0u, 0u, 0u, 0u);
+  }
+}
+__global__ __launch_bounds__(256) void refresh_sph_slots_kernel(const uint4 *sphs, const uint2 *sph_meta, uint64_t n_sphs,
+                                                                const uint32_t *sph_slot, uint4 *slots) {
+  for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < n_sphs; i += (uint64_t)gridDim.x * 256u) {
+    uint4 *p = slots + 4 * (size_t)sph_slot[i];
+    const uint2 m = sph_meta[i];
+    p[0] = sphs[i];
+    p[1] = make_uint4(m.x, m.y, 0u, 0u);
+  }
+}
+
+hipError_t grow(void **p, size_t *cap, size_t bytes) {
+  if (*cap >= bytes) return hipSuccess;
+  (void)hipFree(*p);
+  *p = nullptr;
+  *cap = 0;
+  hipError_t e = hipMalloc(p, bytes ? bytes : 4);
+  if (e == hipSuccess) *cap = bytes ? bytes : 4;
+  return e;
+}
+
 }  // namespace
 
 namespace rtgpu {
@@ -95,18 +139,23 @@ namespace rtgpu {
 // slot tree was made, 0 with out->n_slots == 0 when this tree has no slot form (a leaf of more than four primitives,
 // a box more than 65504 wide, 2^24 slots or more), 2 on a HIP error.  out->d_slots is kept and reused (grow-only);
 // the temporaries come from `pool` when there is one (a loop that refits every frame asks for the same sizes each time).
-int build_slot_tree_device(const void *d_nodes4, uint64_t n4, const void *d_tris, const void *d_sphs, const void *d_sph_meta,
-                           SlotTreeDevice *out, DevPool *pool, void *stream_, std::string &err) {
+int build_slot_tree_device(const void *d_nodes4, uint64_t n4, const void *d_tris, uint64_t n_tris, const void *d_sphs,
+                           const void *d_sph_meta, uint64_t n_sphs, SlotTreeDevice *out, DevPool *pool, void *stream_, std::string &err) {
   hipStream_t stream = (hipStream_t)stream_;
   out->n_slots = 0;
+  out->layout_valid = false;
   if (n4 == 0 || n4 >= (1ull << 24)) return 0;
   const uint32_t n = (uint32_t)n4;
-  uint32_t *d_fam = nullptr, *d_base = nullptr, *d_slot_of = nullptr, *d_bad = nullptr;
+  uint32_t *d_fam = nullptr, *d_bad = nullptr;
   void *d_tmp = nullptr;
   size_t tmp_bytes = 0;
-  hipError_t e = dev_get(pool, (void **)&d_fam, (size_t)n * 4);
-  if (e == hipSuccess) e = dev_get(pool, (void **)&d_base, (size_t)n * 4);
-  if (e == hipSuccess) e = dev_get(pool, (void **)&d_slot_of, (size_t)n * 4);
+  // the layout (kept in `out` for the refreshes after refits): family base and slot per node, slot per primitive
+  hipError_t e = grow((void **)&out->d_base, &out->cap_base, (size_t)n * 4);
+  if (e == hipSuccess) e = grow((void **)&out->d_slot_of, &out->cap_slot_of, (size_t)n * 4);
+  if (e == hipSuccess) e = grow((void **)&out->d_tri_slot, &out->cap_tri_slot, (size_t)n_tris * 4);
+  if (e == hipSuccess) e = grow((void **)&out->d_sph_slot, &out->cap_sph_slot, (size_t)n_sphs * 4);
+  uint32_t *const d_base = out->d_base, *const d_slot_of = out->d_slot_of;
+  if (e == hipSuccess) e = dev_get(pool, (void **)&d_fam, (size_t)n * 4);
   if (e == hipSuccess) e = dev_get(pool, (void **)&d_bad, 4);
   if (e == hipSuccess) e = hipMemsetAsync(d_bad, 0, 4, stream);
   if (e == hipSuccess) e = rocprim::exclusive_scan(nullptr, tmp_bytes, d_fam, d_base, 0u, (size_t)n, rocprim::plus<uint32_t>(), stream);
@@ -137,17 +186,66 @@ int build_slot_tree_device(const void *d_nodes4, uint64_t n4, const void *d_tris
     if (e == hipSuccess) {
       hipLaunchKernelGGL(child_slots_kernel, dim3(blocks), dim3(256), 0, stream, (const rtgpu_node4 *)d_nodes4, n, d_base, d_slot_of, d_bad);
       hipLaunchKernelGGL(write_slots_kernel, dim3(blocks), dim3(256), 0, stream, (const rtgpu_node4 *)d_nodes4, n, d_base, d_slot_of,
-                         (const uint4 *)d_tris, (const uint4 *)d_sphs, (const uint2 *)d_sph_meta, (uint4 *)out->d_slots, d_bad);
+                         (const uint4 *)d_tris, (const uint4 *)d_sphs, (const uint2 *)d_sph_meta, (uint4 *)out->d_slots,
+                         out->d_tri_slot, out->d_sph_slot, d_bad);
       e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
     usable = e == hipSuccess && !bad;
   }
-  dev_put(pool, d_fam); dev_put(pool, d_base); dev_put(pool, d_slot_of); dev_put(pool, d_bad); dev_put(pool, d_tmp);
+  dev_put(pool, d_fam); dev_put(pool, d_bad); dev_put(pool, d_tmp);
   if (e != hipSuccess) { err = std::string("slot tree: ") + hipGetErrorString(e); return 2; }
-  if (usable) out->n_slots = n_slots;
+  if (usable) {
+    out->n_slots = n_slots;
+    out->layout_slots = n_slots;
+    out->layout_valid = true;
+    out->layout_n4 = n4; out->layout_tris = n_tris; out->layout_sphs = n_sphs;
+  }
   return 0;
+}
+
+// After a refit (the same four-wide topology and primitive order: layout_valid, same counts): every slot rewritten in place.
+// Returns like build_slot_tree_device; out->n_slots == 0 if a box no longer has a slot form (the layout stays valid).
+int refresh_slot_tree_device(const void *d_nodes4, const void *d_tris, const void *d_sphs, const void *d_sph_meta,
+                             SlotTreeDevice *out, DevPool *pool, void *stream_, std::string &err) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const uint64_t n_slots = out->layout_slots;
+  out->n_slots = 0;
+  if (!out->layout_valid || !out->d_slots) { err = "internal: slot tree refresh without a layout"; return 2; }
+  const uint32_t n = (uint32_t)out->layout_n4;
+  uint32_t *d_bad = nullptr, bad = 0;
+  hipError_t e = dev_get(pool, (void **)&d_bad, 4);
+  if (e == hipSuccess) e = hipMemsetAsync(d_bad, 0, 4, stream);
+  if (e == hipSuccess) {
+    unsigned blocks = (unsigned)((n + 255u) / 256u);
+    if (blocks > 16384u) blocks = 16384u;
+    hipLaunchKernelGGL(refresh_node_slots_kernel, dim3(blocks), dim3(256), 0, stream, (const rtgpu_node4 *)d_nodes4, n, out->d_base,
+                       out->d_slot_of, (uint4 *)out->d_slots, d_bad);
+    if (out->layout_tris) {
+      uint64_t b = (out->layout_tris * 4 + 255) / 256;
+      hipLaunchKernelGGL(refresh_tri_slots_kernel, dim3((unsigned)(b < 65536 ? b : 65536)), dim3(256), 0, stream, (const uint4 *)d_tris,
+                         out->layout_tris, out->d_tri_slot, (uint4 *)out->d_slots);
+    }
+    if (out->layout_sphs) {
+      uint64_t b = (out->layout_sphs + 255) / 256;
+      hipLaunchKernelGGL(refresh_sph_slots_kernel, dim3((unsigned)(b < 16384 ? b : 16384)), dim3(256), 0, stream, (const uint4 *)d_sphs,
+                         (const uint2 *)d_sph_meta, out->layout_sphs, out->d_sph_slot, (uint4 *)out->d_slots);
+    }
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  dev_put(pool, d_bad);
+  if (e != hipSuccess) { err = std::string("slot tree refresh: ") + hipGetErrorString(e); return 2; }
+  if (!bad) out->n_slots = n_slots;
+  return 0;
+}
+
+void free_slot_tree_device(SlotTreeDevice *out) {
+  (void)hipFree(out->d_slots); (void)hipFree(out->d_base); (void)hipFree(out->d_slot_of);
+  (void)hipFree(out->d_tri_slot); (void)hipFree(out->d_sph_slot);
+  *out = SlotTreeDevice();
 }
 
 }  // namespace rtgpu

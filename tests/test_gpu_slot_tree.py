@@ -152,6 +152,31 @@ def test_slot_tree_follows_a_refit(ra, oracle, gpu_ctx):
         assert not np.array_equal(bits(a), bits(first))
 
 
+def test_refit_before_the_first_frame_of_a_new_scene(ra, oracle, gpu_ctx):
+    """The layout of a slot tree (kept for the in-place refresh after a refit) belongs to ONE scene: a scene uploaded after it and
+    refitted before any frame was traced gets a slot tree of its own, not a refresh into the old layout."""
+    from test_refit import _moved
+    first, cam = ra.Scene.builtin(1, param=5, aspect=1.5)
+    second, cam2 = ra.Scene.builtin(2, param=4, aspect=1.5)
+    st = ra.default_settings(60, 40, spp=1, max_depth=4, flags=ra.FLAG_STATS)
+    gpu_ctx.upload(first)
+    gpu_ctx.render(cam, st)                       # the first scene's slot tree and layout exist
+    gpu_ctx.upload(second)
+    gpu_ctx.refit(_moved(ra, second))             # ... and must not be refreshed with the second scene's boxes
+    fs = gpu_ctx.flat_scene()
+    got, want = gpu_ctx.debug_slot_tree(), oracle.slot_tree(fs.c)
+    assert got is not None and np.array_equal(got, want)
+    a, ia, sa = gpu_ctx.render(cam2, st)
+    b, ib, sb = oracle.render(fs.c, cam2, st, threads=8)
+    assert_bit_equal(a, b, "second scene after a refit")
+    assert np.array_equal(ia, ib) and sa.as_dict() == sb
+    # two refits in a row without a frame between them, then back: the refresh is idempotent
+    gpu_ctx.refit(second)
+    gpu_ctx.refit(_moved(ra, second, seed=3))
+    gpu_ctx.refit(second)
+    assert np.array_equal(gpu_ctx.debug_slot_tree(), oracle.slot_tree(gpu_ctx.flat_scene().c))
+
+
 def test_tree_without_a_slot_form_runs_on_the_four_wide_nodes(ra, oracle, gpu_ctx):
     """A scene 400 000 units wide: the top boxes are farther from their origin than binary16 reaches, so there is no slot
     tree; kernel and oracle both traverse the four-wide nodes and agree, counters included."""
