@@ -55,14 +55,18 @@ __global__ __launch_bounds__(256) void child_slots_kernel(const rtgpu_node4 *n4,
   }
 }
 
+// every node writes its own slot and tells each primitive of its leaf children which slot is its (the primitives are copied by
+// the kernels below, which read the leaf-ordered arrays in order)
 __global__ __launch_bounds__(256) void write_slots_kernel(const rtgpu_node4 *n4, uint32_t n, const uint32_t *base, const uint32_t *slot_of,
-                                                          const uint4 *tris, const uint4 *sphs, const uint2 *sph_meta,
-                                                          uint4 *slots, uint32_t *tri_slot, uint32_t *sph_slot, uint32_t *bad) {
+                                                          uint4 *slots, uint64_t n_slots, uint32_t *tri_slot, uint64_t n_tris,
+                                                          uint32_t *sph_slot, uint64_t n_sphs, uint32_t *bad) {
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
     const rtgpu_node4 nd = n4[i];
     const uint32_t family = 1u + base[i];
     uint32_t w[16];
     if (!rtgpu::make_node_slot(nd, family, w)) { atomicOr(bad, 4u); continue; }
+    // (a well-formed tree fills exactly n_slots slots; anything else - a node no parent names, a family past the end - is reported)
+    if (slot_of[i] >= n_slots || family > n_slots) { atomicOr(bad, 8u); continue; }
     uint4 *dst = slots + 4 * (size_t)slot_of[i];
     for (int q = 0; q < 4; q++) dst[q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
     uint32_t at = family;
@@ -71,21 +75,9 @@ __global__ __launch_bounds__(256) void write_slots_kernel(const rtgpu_node4 *n4,
       (void)rtgpu::slot_child(nd, k, &c);
       if (c.size && (c.ref & RTGPU_REF_LEAF)) {
         const uint32_t first = RTGPU_REF_FIRST(c.ref);
-        for (uint32_t j = 0; j < c.size; j++) {
-          uint4 *p = slots + 4 * (size_t)(at + j);
-          if (c.ref & RTGPU_REF_SPHERE) {
-            sph_slot[first + j] = at + j;
-            const uint2 m = sph_meta[first + j];
-            p[0] = sphs[first + j];
-            p[1] = make_uint4(m.x, m.y, 0u, 0u);
-            p[2] = p[3] = make_uint4(0u, 0u, 0u, 0u);
-          } else {
-            tri_slot[first + j] = at + j;
-            const uint4 *t = tris + 3 * (size_t)(first + j);
-            p[0] = t[0]; p[1] = t[1]; p[2] = t[2];
-            p[3] = make_uint4(0u, 0u, 0u, 0u);
-          }
-        }
+        const bool sphere = (c.ref & RTGPU_REF_SPHERE) != 0;
+        if ((uint64_t)first + c.size > (sphere ? n_sphs : n_tris) || (uint64_t)at + c.size > n_slots) { atomicOr(bad, 8u); continue; }
+        for (uint32_t j = 0; j < c.size; j++) (sphere ? sph_slot : tri_slot)[first + j] = at + j;
       }
       at += c.size;
     }
@@ -103,22 +95,43 @@ __global__ __launch_bounds__(256) void refresh_node_slots_kernel(const rtgpu_nod
   }
 }
 // four threads per triangle: quarter q of the record to quarter q of its slot (the fourth quarter of a slot is zero)
-__global__ __launch_bounds__(256) void refresh_tri_slots_kernel(const uint4 *tris, uint64_t n_tris, const uint32_t *tri_slot, uint4 *slots) {
+__global__ __launch_bounds__(256) void refresh_tri_slots_kernel(const uint4 *tris, uint64_t n_tris, const uint32_t *tri_slot, uint4 *slots,
+                                                                uint64_t n_slots, uint32_t *bad) {
   const uint64_t total = n_tris * 4;
   for (uint64_t k = (uint64_t)blockIdx.x * 256u + threadIdx.x; k < total; k += (uint64_t)gridDim.x * 256u) {
     const uint64_t t = k >> 2;
-    const uint32_t q = (uint32_t)k & 3u;
-    slots[4 * (size_t)tri_slot[t] + q] = q < 3u ? tris[3 * t + q] : make_uint4(0u, 0u, 0u, 0u);
+    const uint32_t q = (uint32_t)k & 3u, at = tri_slot[t];
+    if (at >= n_slots) { if (q == 0) atomicOr(bad, 16u); continue; }  // a primitive no leaf names
+    slots[4 * (size_t)at + q] = q < 3u ? tris[3 * t + q] : make_uint4(0u, 0u, 0u, 0u);
   }
 }
 __global__ __launch_bounds__(256) void refresh_sph_slots_kernel(const uint4 *sphs, const uint2 *sph_meta, uint64_t n_sphs,
-                                                                const uint32_t *sph_slot, uint4 *slots) {
+                                                                const uint32_t *sph_slot, uint4 *slots, uint64_t n_slots, uint32_t *bad) {
   for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < n_sphs; i += (uint64_t)gridDim.x * 256u) {
-    uint4 *p = slots + 4 * (size_t)sph_slot[i];
+    const uint32_t at = sph_slot[i];
+    if (at >= n_slots) { atomicOr(bad, 16u); continue; }
+    uint4 *p = slots + 4 * (size_t)at;
     const uint2 m = sph_meta[i];
     p[0] = sphs[i];
     p[1] = make_uint4(m.x, m.y, 0u, 0u);
+    p[2] = p[3] = make_uint4(0u, 0u, 0u, 0u);
   }
+}
+
+// the primitives into their slots (full build and refresh alike)
+hipError_t copy_primitives(const void *d_tris, const void *d_sphs, const void *d_sph_meta, const rtgpu::SlotTreeDevice *t, uint64_t n_tris,
+                           uint64_t n_sphs, uint64_t n_slots, uint32_t *d_bad, hipStream_t stream) {
+  if (n_tris) {
+    uint64_t b = (n_tris * 4 + 255) / 256;
+    hipLaunchKernelGGL(refresh_tri_slots_kernel, dim3((unsigned)(b < 65536 ? b : 65536)), dim3(256), 0, stream, (const uint4 *)d_tris,
+                       n_tris, t->d_tri_slot, (uint4 *)t->d_slots, n_slots, d_bad);
+  }
+  if (n_sphs) {
+    uint64_t b = (n_sphs + 255) / 256;
+    hipLaunchKernelGGL(refresh_sph_slots_kernel, dim3((unsigned)(b < 16384 ? b : 16384)), dim3(256), 0, stream, (const uint4 *)d_sphs,
+                       (const uint2 *)d_sph_meta, n_sphs, t->d_sph_slot, (uint4 *)t->d_slots, n_slots, d_bad);
+  }
+  return hipGetLastError();
 }
 
 hipError_t grow(void **p, size_t *cap, size_t bytes) {
@@ -162,18 +175,10 @@ int build_slot_tree_device(const void *d_nodes4, uint64_t n4, const void *d_tris
   if (e == hipSuccess) e = dev_get(pool, &d_tmp, tmp_bytes ? tmp_bytes : 64);
   unsigned blocks = (unsigned)((n + 255u) / 256u);
   if (blocks > 16384u) blocks = 16384u;
-  uint32_t last[2] = {0, 0}, bad = 0;
-  if (e == hipSuccess) {
-    hipLaunchKernelGGL(family_sizes_kernel, dim3(blocks), dim3(256), 0, stream, (const rtgpu_node4 *)d_nodes4, n, d_fam, d_bad);
-    e = hipGetLastError();
-  }
-  if (e == hipSuccess) e = rocprim::exclusive_scan(d_tmp, tmp_bytes, d_fam, d_base, 0u, (size_t)n, rocprim::plus<uint32_t>(), stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(&last[0], d_base + (n - 1), 4, hipMemcpyDeviceToHost, stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(&last[1], d_fam + (n - 1), 4, hipMemcpyDeviceToHost, stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(stream);
-  const uint64_t n_slots = 1ull + last[0] + last[1];
-  bool usable = e == hipSuccess && !bad && n_slots < (1ull << 24);
+  uint32_t bad = 0;
+  // every node but the root is some node's inner child and every primitive sits in one leaf: the slots are known without a look
+  const uint64_t n_slots = n4 + n_tris + n_sphs;
+  bool usable = e == hipSuccess && n_slots < (1ull << 24);
   if (usable) {
     const size_t bytes = (size_t)n_slots * 64;
     if (out->cap_bytes < bytes) {
@@ -183,13 +188,22 @@ int build_slot_tree_device(const void *d_nodes4, uint64_t n4, const void *d_tris
       e = hipMalloc(&out->d_slots, bytes);
       if (e == hipSuccess) out->cap_bytes = bytes;
     }
+    // (a primitive that no leaf names keeps an impossible slot and is reported)
+    if (e == hipSuccess) e = hipMemsetAsync(out->d_slot_of, 0xFF, (size_t)n * 4, stream);
+    if (e == hipSuccess && n_tris) e = hipMemsetAsync(out->d_tri_slot, 0xFF, (size_t)n_tris * 4, stream);
+    if (e == hipSuccess && n_sphs) e = hipMemsetAsync(out->d_sph_slot, 0xFF, (size_t)n_sphs * 4, stream);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(family_sizes_kernel, dim3(blocks), dim3(256), 0, stream, (const rtgpu_node4 *)d_nodes4, n, d_fam, d_bad);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = rocprim::exclusive_scan(d_tmp, tmp_bytes, d_fam, d_base, 0u, (size_t)n, rocprim::plus<uint32_t>(), stream);
     if (e == hipSuccess) {
       hipLaunchKernelGGL(child_slots_kernel, dim3(blocks), dim3(256), 0, stream, (const rtgpu_node4 *)d_nodes4, n, d_base, d_slot_of, d_bad);
       hipLaunchKernelGGL(write_slots_kernel, dim3(blocks), dim3(256), 0, stream, (const rtgpu_node4 *)d_nodes4, n, d_base, d_slot_of,
-                         (const uint4 *)d_tris, (const uint4 *)d_sphs, (const uint2 *)d_sph_meta, (uint4 *)out->d_slots,
-                         out->d_tri_slot, out->d_sph_slot, d_bad);
+                         (uint4 *)out->d_slots, n_slots, out->d_tri_slot, n_tris, out->d_sph_slot, n_sphs, d_bad);
       e = hipGetLastError();
     }
+    if (e == hipSuccess) e = copy_primitives(d_tris, d_sphs, d_sph_meta, out, n_tris, n_sphs, n_slots, d_bad, stream);
     if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
     usable = e == hipSuccess && !bad;
@@ -222,17 +236,7 @@ int refresh_slot_tree_device(const void *d_nodes4, const void *d_tris, const voi
     if (blocks > 16384u) blocks = 16384u;
     hipLaunchKernelGGL(refresh_node_slots_kernel, dim3(blocks), dim3(256), 0, stream, (const rtgpu_node4 *)d_nodes4, n, out->d_base,
                        out->d_slot_of, (uint4 *)out->d_slots, d_bad);
-    if (out->layout_tris) {
-      uint64_t b = (out->layout_tris * 4 + 255) / 256;
-      hipLaunchKernelGGL(refresh_tri_slots_kernel, dim3((unsigned)(b < 65536 ? b : 65536)), dim3(256), 0, stream, (const uint4 *)d_tris,
-                         out->layout_tris, out->d_tri_slot, (uint4 *)out->d_slots);
-    }
-    if (out->layout_sphs) {
-      uint64_t b = (out->layout_sphs + 255) / 256;
-      hipLaunchKernelGGL(refresh_sph_slots_kernel, dim3((unsigned)(b < 16384 ? b : 16384)), dim3(256), 0, stream, (const uint4 *)d_sphs,
-                         (const uint2 *)d_sph_meta, out->layout_sphs, out->d_sph_slot, (uint4 *)out->d_slots);
-    }
-    e = hipGetLastError();
+    e = copy_primitives(d_tris, d_sphs, d_sph_meta, out, out->layout_tris, out->layout_sphs, n_slots, d_bad, stream);
   }
   if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, stream);
   if (e == hipSuccess) e = hipStreamSynchronize(stream);
