@@ -27,6 +27,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "dev_pool.h"
@@ -57,6 +58,10 @@ constexpr int      kBlock      = RTGPU_KBLOCK;
 #define RTGPU_KBLOCK2 768
 #endif
 constexpr int      kBlock2     = RTGPU_KBLOCK2;    // threads per block of MODE 8 (two rays per lane): 12 waves, three per SIMD
+// MODE 13: TWO blocks of kBlock6 threads per CU, each with its own copy of the scene in LDS: 24 waves per CU, six per SIMD
+// (a twelve-wave block is three waves on every SIMD, so two of them are co-resident: tools/ubench/residency.hip)
+constexpr int      kBlock6     = 768;
+constexpr int      kLdsBytes6  = 160 * 1024 / 2;
 constexpr int      kBlocksPerCU = RTGPU_BLOCKS_PER_CU; // one block per CU: 16 waves share one LDS copy of the top of the BVH
 constexpr int      kStackLds   = 32;   // most entries per lane the LDS stack may get (4 KiB per entry per block)
 constexpr int      kLdsBytes   = 160 * 1024 / kBlocksPerCU - (kBlocksPerCU > 1 ? 2048 : 0);  // LDS per CU on gfx950, shared equally by the CU's blocks
@@ -83,6 +88,7 @@ constexpr int      kTinyNodes = 512, kTinySphs = 496, kTinyTris = 16;
 constexpr int      kTinySphAt = 4 * kTinyNodes, kTinyTriAt = kTinySphAt + kTinySphs, kTinyTriNAt = kTinyTriAt + 3 * kTinyTris,
                    kTinySphMatAt = kTinyTriNAt + kTinyTris, kTinyTriMatAt = kTinySphMatAt + 2 * kTinySphs,
                    kTinyMetaAt = kTinyTriMatAt + 2 * kTinyTris, kTinyEnd = kTinyMetaAt + kTinySphs / 2;
+constexpr int      kTinySphAt6 = 3 * kTinyNodes + kTinyNodes / 2, kTinyEnd6 = kTinyEnd - kTinyNodes / 2;  // MODE 13: 8-byte fourth plane
 static_assert(kTinyEnd * 16 <= 65536, "MODE 7: every array within reach of a 16-bit ds_read offset");
 // MODE 5 of the trace kernel: the first kWideCached four-wide nodes (the top of the tree: both
 // collapses number it breadth first) live in LDS as six 16-byte planes this many nodes apart
@@ -292,8 +298,11 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 // is always written above the top (kept only if both children were hit) and the
 // top is always read (used only if neither was).
 // STRIDE: words between consecutive entries of one stack (the threads of the block x the rays a lane traverses).
-template <bool LDS_ONLY, int STRIDE>
+// E: the type of an LDS entry.  MODE 13 keeps its references in 16 bits (int16_t: a ds_read_i16 gives back the sign-extended
+// 32-bit form the kernel works on), which halves the stacks; only the LDS_ONLY form may.
+template <bool LDS_ONLY, int STRIDE, typename E = uint32_t>
 struct Stack {
+  static_assert(LDS_ONLY || sizeof(E) == 4, "16-bit entries: LDS-only stacks");
   uint32_t *lds;        // &lds_stack[tid]
   uint32_t *ovf;        // &ovf[global thread]
   uint32_t ovf_stride;  // threads in the grid
@@ -301,7 +310,7 @@ struct Stack {
   int sp;               // next free entry; >= 1 while a traversal is running (overflow-capable form)
   // LDS_ONLY form: the stack pointer IS the LDS address of the top entry (32-bit, explicit
   // address space), so a step needs no index -> address arithmetic
-  typedef __attribute__((address_space(3))) uint32_t lds_u32;
+  typedef __attribute__((address_space(3))) E lds_u32;
   lds_u32 *top_at;      // &entry[sp - 1] of this lane
   lds_u32 *base_at;     // &entry[0] of this lane (the sentinel)
   __device__ __forceinline__ void reset() {
@@ -318,12 +327,12 @@ struct Stack {
   }
   // the entry a pop would return (LDS form), read at the START of a node step so that the
   // LDS round trip overlaps the node fetch instead of following the slab test
-  __device__ __forceinline__ uint32_t peek() const { return LDS_ONLY ? top_at[0] : 0u; }
+  __device__ __forceinline__ uint32_t peek() const { return LDS_ONLY ? (uint32_t)(int32_t)top_at[0] : 0u; }
   // node step: push `far_c` if both children were hit, pop if none was
   __device__ __forceinline__ uint32_t step(bool both, bool none, uint32_t near_c, uint32_t far_c, uint32_t top) {
     if (LDS_ONLY) {
       // one address: top at [0] (read by peek()), free entry at [STRIDE] (immediate offset)
-      top_at[STRIDE] = far_c;
+      top_at[STRIDE] = (E)far_c;
       top_at += both ? STRIDE : (none ? -STRIDE : 0);
       return none ? top : near_c;
     }
@@ -447,22 +456,25 @@ __device__ __forceinline__ void wave_tick(unsigned lane, unsigned long long &c) 
 // (The slot-exchange experiment of round 2 - modes 8-10 then, profiles/r02/experiments.txt H and J -
 // was a measured negative and is gone from the source.)
 template <int STATS, int REFILL, int MODE>
-__global__ __launch_bounds__(MODE == 8 ? kBlock2 : (MODE == 11 || MODE == 12) ? kBlockSlots : kBlock)
-__attribute__((amdgpu_waves_per_eu(MODE == 8 ? kBlock2 * RTGPU_BLOCKS_PER_CU / 256
+__global__ __launch_bounds__(MODE == 8 ? kBlock2 : MODE == 13 ? kBlock6 : (MODE == 11 || MODE == 12) ? kBlockSlots : kBlock)
+__attribute__((amdgpu_waves_per_eu(MODE == 8 ? kBlock2 * RTGPU_BLOCKS_PER_CU / 256 : MODE == 13 ? (STATS == 0 ? 6 : 3)
                                    : (MODE == 11 || MODE == 12) ? (STATS == 0 ? kSlotWaves : kSlotWaves - 1) : RTGPU_WAVES_PER_EU,
-                                   MODE == 8 ? kBlock2 * RTGPU_BLOCKS_PER_CU / 256
+                                   MODE == 8 ? kBlock2 * RTGPU_BLOCKS_PER_CU / 256 : MODE == 13 ? (STATS == 0 ? 6 : 3)
                                    : (MODE == 11 || MODE == 12) ? (STATS == 0 ? kSlotWaves : kSlotWaves - 1) : RTGPU_WAVES_PER_EU_MAX)))
 void trace_kernel(const KParams P) {
-  constexpr bool LDS_ONLY = MODE == 1 || MODE == 2 || MODE == 4 || MODE == 6 || MODE == 7 || MODE == 8 || MODE == 10 || MODE == 12,
-                 SMALL = MODE == 2 || MODE == 7 || MODE == 8,
-                 TINY = MODE == 7 || MODE == 8, PACKED = MODE == 3 || MODE == 4,
+  constexpr bool LDS_ONLY = MODE == 1 || MODE == 2 || MODE == 4 || MODE == 6 || MODE == 7 || MODE == 8 || MODE == 10 || MODE == 12 || MODE == 13,
+                 SMALL = MODE == 2 || MODE == 7 || MODE == 8 || MODE == 13,
+                 TINY = MODE == 7 || MODE == 8 || MODE == 13, PACKED = MODE == 3 || MODE == 4,
                  WIDE = MODE == 5 || MODE == 6 || MODE == 9 || MODE == 10, HYBRID = MODE == 5 || MODE == 9 || MODE == 11,
-                 SLOT128 = MODE == 9 || MODE == 10, SLOTS = MODE == 11 || MODE == 12;
+                 SLOT128 = MODE == 9 || MODE == 10, SLOTS = MODE == 11 || MODE == 12,
+                 T6 = MODE == 13;  // the scene in LDS twice per CU, six waves per SIMD (see the mode list above)
   // leaf references: bit 31 leaf, bit 30 sphere, then count - 1 and the first primitive (rtgpu_format.h); the slot tree keeps
-  // two bits of count and 28 of slot
-  constexpr uint32_t CNT_SHIFT = SLOTS ? 28u : 27u, CNT_MASK = SLOTS ? 3u : 7u, FIRST_MASK = (1u << CNT_SHIFT) - 1u;
+  // two bits of count and 28 of slot.  MODE 13 turns the references of its LDS copy into the sign-extended 16-bit form
+  // (tiny_ref below): bit 15 leaf, bit 14 sphere, count - 1 in bits 11-13, the first primitive (< 2048) below
+  constexpr uint32_t CNT_SHIFT = T6 ? 11u : SLOTS ? 28u : 27u, CNT_MASK = SLOTS ? 3u : 7u, FIRST_MASK = (1u << CNT_SHIFT) - 1u,
+                     REF_SPH = T6 ? (1u << 14) : RTGPU_REF_SPHERE;
   constexpr int R = MODE == 8 ? 2 : 1;                  // rays a lane traverses in lock step
-  constexpr int BLOCK = MODE == 8 ? kBlock2 : SLOTS ? kBlockSlots : kBlock;   // threads per block
+  constexpr int BLOCK = MODE == 8 ? kBlock2 : T6 ? kBlock6 : SLOTS ? kBlockSlots : kBlock;   // threads per block
   constexpr int STRIDE = BLOCK * R;                     // words between consecutive entries of one stack
 #ifdef RTGPU_NO_HIT_NORMAL  // experiments: shading fetches the triangle again
   constexpr bool KEEP_N = false;
@@ -484,11 +496,12 @@ void trace_kernel(const KParams P) {
   // Slot-tree modes: the item's running sum and the path's throughput live in LDS behind the stacks (six words per lane, touched
   // by the shading pass and when the item ends), not in registers: six of the registers that stood between these modes and a
   // fifth wave per SIMD
-  constexpr bool SUM_LDS = SLOTS, DIET = SLOTS;
+  constexpr bool SUM_LDS = SLOTS, DIET = SLOTS || T6;
   typedef __attribute__((address_space(3))) float lds_f32;
-  lds_f32 *const lds_sum = (lds_f32 *)(smem + P.stack_lds * STRIDE) + threadIdx.x;
+  const uint32_t stack_words = T6 ? P.stack_lds * (STRIDE / 2) : P.stack_lds * STRIDE;  // MODE 13: 16-bit entries
+  lds_f32 *const lds_sum = (lds_f32 *)(smem + stack_words) + threadIdx.x;
   lds_f32 *const lds_thr = lds_sum + 3 * BLOCK;
-  lds_f4 *const node_cache = (lds_f4 *)(smem + P.stack_lds * STRIDE + (SUM_LDS ? kPathLdsWords * BLOCK : 0));
+  lds_f4 *const node_cache = (lds_f4 *)(smem + stack_words + (SUM_LDS ? kPathLdsWords * BLOCK : 0));
   auto thr_get = [&](const V3 &reg) __attribute__((always_inline)) {
     return SUM_LDS ? mk(lds_thr[0], lds_thr[BLOCK], lds_thr[2 * BLOCK]) : reg;
   };
@@ -519,7 +532,8 @@ void trace_kernel(const KParams P) {
 
   // state of one ray of the lane: the work item it belongs to, its path, and its traversal
   // (which survives an early exit from the traversal loop)
-  typedef Stack<LDS_ONLY, STRIDE> StackT;
+  typedef typename std::conditional<T6, int16_t, uint32_t>::type StackEntry;
+  typedef Stack<LDS_ONLY, STRIDE, StackEntry> StackT;
   struct Ray {
     bool done, alive, have_pixel, pixel_valid;
     // the work item: pixel (DIET: x | y << 16 in px; both below 65536, checked at launch), its output slot, the sample being traced and the
@@ -531,6 +545,9 @@ void trace_kernel(const KParams P) {
     Rng rng;
     V3 new_dir;  // unnormalised direction of the segment about to start
     f2 inv_xy, inv_zx, inv_yz, noi_xy, noi_zx, noi_yz;
+    // MODE 13 instead of those twelve: (1/d.x, 1/d.y), (-o.x/d.x, -o.y/d.y), (1/d.z, -o.z/d.z) - its LDS nodes are laid out so
+    // that v_pk_fma_f32 picks the halves it needs with op_sel (node step below): six registers fewer across the loop
+    f2 inv_a, noi_a, zz;
     float tbest;
     uint32_t cur;
     // closest hit so far: the leaf cursor at the time of the hit (type bit + slot of the
@@ -556,17 +573,18 @@ void trace_kernel(const KParams P) {
     S.new_dir = mk(0.f, 0.f, 1.f);
     S.inv_xy = mk2(1.f, 1.f); S.inv_zx = S.inv_xy; S.inv_yz = S.inv_xy;
     S.noi_xy = mk2(0.f, 0.f); S.noi_zx = S.noi_xy; S.noi_yz = S.noi_xy;
+    S.inv_a = mk2(1.f, 1.f); S.noi_a = mk2(0.f, 0.f); S.zz = mk2(1.f, 0.f);
     S.tbest = kTMax;
     S.cur = kDone; S.hit_ref = kDone; S.hit_mat = 0u;
     S.hit_n = mk(0.f, 0.f, 1.f); S.hit_prim = 0u;
     S.stk.lds = lds_stack + r * BLOCK + tid;
-    S.stk.base_at = (typename StackT::lds_u32 *)(lds_stack + r * BLOCK + tid);
+    S.stk.base_at = (typename StackT::lds_u32 *)smem + r * BLOCK + tid;
     S.stk.top_at = S.stk.base_at;
     S.stk.ovf_stride = gridDim.x * BLOCK;
     S.stk.ovf = P.ovf_stack + (size_t)blockIdx.x * BLOCK + tid;
     S.stk.sp = 1;
     S.stk.lds_entries = (int)P.stack_lds;
-    lds_stack[r * BLOCK + tid] = kDone;  // sentinel under every stack (never overwritten)
+    S.stk.base_at[0] = (StackEntry)kDone;  // sentinel under every stack (never overwritten)
   };
   init_ray(ray0, 0);
   init_ray(ray1, R - 1);  // (R == 1: the same words again; ray1 is then never used)
@@ -584,15 +602,38 @@ void trace_kernel(const KParams P) {
   // vs 142 for node-major LDS and 181 through the vector L1, tools/ubench).
   const uint32_t n_cached = (SMALL || HYBRID) ? P.n_cached : 0u;
   constexpr uint32_t plane = (uint32_t)(TINY ? kTinyNodes : kSmallNodes);  // nodes per plane
-  if (SMALL)
+  typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+  typedef __attribute__((address_space(3))) u2 lds_u2;
+  // MODE 13: offsets of the arrays behind the node planes (16-byte units); its fourth plane holds the two child references
+  // only (8 bytes per node), the other arrays follow as in kTiny*
+  constexpr int SPH_AT = T6 ? kTinySphAt6 : kTinySphAt, TRI_AT = SPH_AT + kTinySphs, TRIN_AT = TRI_AT + 3 * kTinyTris,
+                SPHMAT_AT = TRIN_AT + kTinyTris, TRIMAT_AT = SPHMAT_AT + 2 * kTinySphs, META_AT = TRIMAT_AT + 2 * kTinyTris;
+  static_assert(!T6 || META_AT + kTinySphs / 2 == kTinyEnd6, "MODE 13: the host sizes the LDS by kTinyEnd6");
+  lds_u2 *const ref_cache = (lds_u2 *)(node_cache + 3 * plane);  // MODE 13
+  if (SMALL && !T6)
     for (uint32_t i = tid; i < n_cached * 4u; i += BLOCK) {
       float4 v = P.nodes[i];
       f4 w = {v.x, v.y, v.z, v.w};
       node_cache[(i & 3u) * plane + (i >> 2)] = w;
     }
+  if (T6) {
+    // the node's twelve planes regrouped per axis: (lo0.x hi0.x lo0.y hi0.y) (lo0.z hi0.z lo1.x hi1.x) (lo1.y hi1.y lo1.z hi1.z),
+    // so that a slab pair needs ONE component of 1/d and of -o/d in both halves of a v_pk_fma_f32 (op_sel), and the two
+    // child references in the sign-extended 16-bit form the stacks of this mode hold
+    auto tiny_ref = [](uint32_t r) {
+      return (int)r >= 0 ? r : (0xFFFF8000u | (((r >> 30) & 1u) << 14) | (((r >> 27) & 7u) << 11) | (r & 0x7FFu));
+    };
+    for (uint32_t i = tid; i < n_cached; i += BLOCK) {
+      const float4 q0 = P.nodes[4u * i], q1 = P.nodes[4u * i + 1u], q2 = P.nodes[4u * i + 2u], q3 = P.nodes[4u * i + 3u];
+      const f4 w0 = {q0.x, q0.w, q0.y, q1.x}, w1 = {q0.z, q1.y, q1.z, q2.y}, w2 = {q1.w, q2.z, q2.x, q2.w};
+      const u2 c = {tiny_ref(__float_as_uint(q3.x)), tiny_ref(__float_as_uint(q3.y))};
+      node_cache[i] = w0; node_cache[plane + i] = w1; node_cache[2u * plane + i] = w2;
+      ref_cache[i] = c;
+    }
+  }
   // MODE 2: the leaf-ordered spheres behind the node planes when they fit: the sphere test is then an
   // LDS read like the node fetch instead of a round trip through the vector L1
-  lds_f4 *const sph_cache = node_cache + 4 * plane;
+  lds_f4 *const sph_cache = node_cache + (TINY ? (uint32_t)SPH_AT : 4 * plane);
   const bool sph_in_lds = TINY || (SMALL && P.sph_cached != 0u);
   if (sph_in_lds)
     for (uint32_t i = tid; i < P.sph_cached; i += BLOCK) {
@@ -602,11 +643,9 @@ void trace_kernel(const KParams P) {
     }
   // MODE 7: and the triangles, and per primitive what shading reads (computed here once per block with the
   // operations shading would use: the same bits)
-  typedef uint32_t u2 __attribute__((ext_vector_type(2)));
-  typedef __attribute__((address_space(3))) u2 lds_u2;
-  lds_f4 *const tri_cache = node_cache + kTinyTriAt, *const trin_cache = node_cache + kTinyTriNAt,
-         *const sphmat_cache = node_cache + kTinySphMatAt, *const trimat_cache = node_cache + kTinyTriMatAt;
-  lds_u2 *const meta_cache = (lds_u2 *)(node_cache + kTinyMetaAt);
+  lds_f4 *const tri_cache = node_cache + TRI_AT, *const trin_cache = node_cache + TRIN_AT,
+         *const sphmat_cache = node_cache + SPHMAT_AT, *const trimat_cache = node_cache + TRIMAT_AT;
+  lds_u2 *const meta_cache = (lds_u2 *)(node_cache + META_AT);
   if (TINY) {
     for (uint32_t i = tid; i < P.tiny_tris * 3u; i += BLOCK) {
       float4 v = P.tris[i];
@@ -713,7 +752,7 @@ void trace_kernel(const KParams P) {
         V3 n;
         uint32_t prim;
         float4 m0, m1;
-        if (S.hit_ref & RTGPU_REF_SPHERE) {
+        if (S.hit_ref & REF_SPH) {
           float4 s;
           if (sph_in_lds) { const f4 w = sph_cache[hit_slot]; s = make_float4(w.x, w.y, w.z, w.w); }
           else if (SLOTS) s = *(const float4 *)(nodes_base + (hit_slot << 6));
@@ -1001,8 +1040,12 @@ void trace_kernel(const KParams P) {
       // |clamp_dir(d)| lies in [1e-30, 1] for every finite direction: inside rcp_fast's verified range
       const V3 inv = mk(rcp_fast(clamp_dir(S.rd.x)), rcp_fast(clamp_dir(S.rd.y)), rcp_fast(clamp_dir(S.rd.z)));
       const V3 noi = mk(-(S.ro.x * inv.x), -(S.ro.y * inv.y), -(S.ro.z * inv.z));
-      S.inv_xy = mk2(inv.x, inv.y); S.inv_zx = mk2(inv.z, inv.x); S.inv_yz = mk2(inv.y, inv.z);
-      S.noi_xy = mk2(noi.x, noi.y); S.noi_zx = mk2(noi.z, noi.x); S.noi_yz = mk2(noi.y, noi.z);
+      if (T6) {
+        S.inv_a = mk2(inv.x, inv.y); S.noi_a = mk2(noi.x, noi.y); S.zz = mk2(inv.z, noi.z);
+      } else {
+        S.inv_xy = mk2(inv.x, inv.y); S.inv_zx = mk2(inv.z, inv.x); S.inv_yz = mk2(inv.y, inv.z);
+        S.noi_xy = mk2(noi.x, noi.y); S.noi_zx = mk2(noi.z, noi.x); S.noi_yz = mk2(noi.y, noi.z);
+      }
       S.tbest = kTMax;
       S.hit_ref = kDone;
       S.cur = 0;  // root
@@ -1228,7 +1271,14 @@ void trace_kernel(const KParams P) {
               // MODE 0/1 (tree larger than the LDS cache) fetch every node through L1: a
               // partial cache measured no gain on the big scenes and costs a
               // test and two branches per step
-              if (SMALL) {
+              if (T6) {
+                const f4 w0 = node_cache[cur], w1 = node_cache[plane + cur], w2 = node_cache[2u * plane + cur];
+                const u2 c = ref_cache[cur];
+                D.q0 = make_float4(w0.x, w0.y, w0.z, w0.w);
+                D.q1 = make_float4(w1.x, w1.y, w1.z, w1.w);
+                D.q2 = make_float4(w2.x, w2.y, w2.z, w2.w);
+                D.c0 = c.x; D.c1 = c.y;
+              } else if (SMALL) {
                 f4 w0 = node_cache[cur], w1 = node_cache[plane + cur], w2 = node_cache[2u * plane + cur],
                    w3 = node_cache[3u * plane + cur];
                 D.q0 = make_float4(w0.x, w0.y, w0.z, w0.w);
@@ -1262,21 +1312,69 @@ void trace_kernel(const KParams P) {
               // the twelve slab fmas as six v_pk_fma_f32 (two IEEE fmas per instruction,
               // bit-identical to fmaf): the node's planes sit in memory in the pair order
               // (x,y)(z,x)(y,z)(x,y)(z,x)(y,z), matched by the pre-paired 1/d and -(o/d)
+              float a0x, a0y, a0z, a1x, a1y, a1z, b0x, b0y, b0z, b1x, b1y, b1z;
+              if (T6) {
+                // planes per axis (see the LDS copy): (lo, hi) of one axis x that axis of 1/d in BOTH halves + that axis of
+                // -o/d in both halves; the same twelve IEEE fmas
+                // (one asm block: between separate asm statements hipcc puts an s_nop per dependence it cannot see into)
+                f2 p0 = mk2(q0.x, q0.y), p1 = mk2(q0.z, q0.w), p2 = mk2(q1.x, q1.y), p3 = mk2(q1.z, q1.w), p4 = mk2(q2.x, q2.y),
+                   p5 = mk2(q2.z, q2.w);
+                asm("v_pk_fma_f32 %0, %0, %6, %7 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"   // x: the low halves of inv_a, noi_a
+                    "v_pk_fma_f32 %1, %1, %6, %7 op_sel:[0,1,1] op_sel_hi:[1,1,1]\n\t"   // y: the high halves
+                    "v_pk_fma_f32 %2, %2, %8, %8 op_sel:[0,0,1] op_sel_hi:[1,0,1]\n\t"   // z: 1/d.z low, -o.z/d.z high, of zz
+                    "v_pk_fma_f32 %3, %3, %6, %7 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+                    "v_pk_fma_f32 %4, %4, %6, %7 op_sel:[0,1,1] op_sel_hi:[1,1,1]\n\t"
+                    "v_pk_fma_f32 %5, %5, %8, %8 op_sel:[0,0,1] op_sel_hi:[1,0,1]"
+                    : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5) : "v"(S.inv_a), "v"(S.noi_a), "v"(S.zz));
+                a0x = p0.x; a1x = p0.y; a0y = p1.x; a1y = p1.y; a0z = p2.x; a1z = p2.y;
+                b0x = p3.x; b1x = p3.y; b0y = p4.x; b1y = p4.y; b0z = p5.x; b1z = p5.y;
+              } else {
               f2 p0 = __builtin_elementwise_fma(mk2(q0.x, q0.y), S.inv_xy, S.noi_xy);  // lo0.x lo0.y
               f2 p1 = __builtin_elementwise_fma(mk2(q0.z, q0.w), S.inv_zx, S.noi_zx);  // lo0.z hi0.x
               f2 p2 = __builtin_elementwise_fma(mk2(q1.x, q1.y), S.inv_yz, S.noi_yz);  // hi0.y hi0.z
               f2 p3 = __builtin_elementwise_fma(mk2(q1.z, q1.w), S.inv_xy, S.noi_xy);  // lo1.x lo1.y
               f2 p4 = __builtin_elementwise_fma(mk2(q2.x, q2.y), S.inv_zx, S.noi_zx);  // lo1.z hi1.x
               f2 p5 = __builtin_elementwise_fma(mk2(q2.z, q2.w), S.inv_yz, S.noi_yz);  // hi1.y hi1.z
-              float a0x = p0.x, a0y = p0.y, a0z = p1.x, a1x = p1.y, a1y = p2.x, a1z = p2.y;
-              float b0x = p3.x, b0y = p3.y, b0z = p4.x, b1x = p4.y, b1y = p5.x, b1z = p5.y;
+              a0x = p0.x; a0y = p0.y; a0z = p1.x; a1x = p1.y; a1y = p2.x; a1z = p2.y;
+              b0x = p3.x; b0y = p3.y; b0z = p4.x; b1x = p4.y; b1y = p5.x; b1z = p5.y;
+              }
               // vmax_/vmin_: the bare instruction for the two operands that hipcc cannot
               // prove canonical (tmin from the kernel arguments, tbest through the loop):
               // the builtin costs an extra v_max x,x per operand per step
-              float tn0 = fmax_(fmax_(fmin_(a0x, a1x), fmin_(a0y, a1y)), vmax_(fmin_(a0z, a1z), tmin));
-              float tf0 = fmin_(fmin_(fmax_(a0x, a1x), fmax_(a0y, a1y)), vmin_(fmax_(a0z, a1z), S.tbest));
-              float tn1 = fmax_(fmax_(fmin_(b0x, b1x), fmin_(b0y, b1y)), vmax_(fmin_(b0z, b1z), tmin));
-              float tf1 = fmin_(fmin_(fmax_(b0x, b1x), fmax_(b0y, b1y)), vmin_(fmax_(b0z, b1z), S.tbest));
+              float tn0, tf0, tn1, tf1;
+              if (T6) {
+                // the asm's results are fma results (never signalling NaNs), which hipcc cannot know: its fminf / fmaxf would
+                // canonicalise each of the twelve first (a v_max_f32 x, x apiece) - so the bare instructions, as vmax_ / vmin_
+                float t1, t2, t3, t4;
+                asm("v_min_f32 %0, %8, %9\n\t"
+                    "v_min_f32 %4, %10, %11\n\t"
+                    "v_min_f32 %5, %12, %13\n\t"
+                    "v_min_f32 %2, %14, %15\n\t"
+                    "v_min_f32 %6, %16, %17\n\t"
+                    "v_min_f32 %7, %18, %19\n\t"
+                    "v_max_f32 %5, %20, %5\n\t"
+                    "v_max_f32 %7, %20, %7\n\t"
+                    "v_max3_f32 %0, %0, %4, %5\n\t"
+                    "v_max3_f32 %2, %2, %6, %7\n\t"
+                    "v_max_f32 %1, %8, %9\n\t"
+                    "v_max_f32 %4, %10, %11\n\t"
+                    "v_max_f32 %5, %12, %13\n\t"
+                    "v_max_f32 %3, %14, %15\n\t"
+                    "v_max_f32 %6, %16, %17\n\t"
+                    "v_max_f32 %7, %18, %19\n\t"
+                    "v_min_f32 %5, %5, %21\n\t"
+                    "v_min_f32 %7, %7, %21\n\t"
+                    "v_min3_f32 %1, %1, %4, %5\n\t"
+                    "v_min3_f32 %3, %3, %6, %7"
+                    : "=&v"(tn0), "=&v"(tf0), "=&v"(tn1), "=&v"(tf1), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4)
+                    : "v"(a0x), "v"(a1x), "v"(a0y), "v"(a1y), "v"(a0z), "v"(a1z), "v"(b0x), "v"(b1x), "v"(b0y), "v"(b1y),
+                      "v"(b0z), "v"(b1z), "s"(tmin), "v"(S.tbest));
+              } else {
+                tn0 = fmax_(fmax_(fmin_(a0x, a1x), fmin_(a0y, a1y)), vmax_(fmin_(a0z, a1z), tmin));
+                tf0 = fmin_(fmin_(fmax_(a0x, a1x), fmax_(a0y, a1y)), vmin_(fmax_(a0z, a1z), S.tbest));
+                tn1 = fmax_(fmax_(fmin_(b0x, b1x), fmin_(b0y, b1y)), vmax_(fmin_(b0z, b1z), tmin));
+                tf1 = fmin_(fmin_(fmax_(b0x, b1x), fmax_(b0y, b1y)), vmin_(fmax_(b0z, b1z), S.tbest));
+              }
               // an empty child (scenes of < 2 primitives) has its box at +inf and can
               // never pass: tfar <= tbest <= FLT_MAX < tnear
               bool h0 = tn0 <= tf0;
@@ -1311,8 +1409,8 @@ void trace_kernel(const KParams P) {
           auto leaf_fetch = [&](Ray &S, LeafData &D) __attribute__((always_inline)) {
             const uint32_t cur = S.cur;
             D.at_leaf = (int)cur < -1;
-            D.at_sph = D.at_leaf && (cur & RTGPU_REF_SPHERE);
-            D.at_tri = D.at_leaf && !(cur & RTGPU_REF_SPHERE);
+            D.at_sph = D.at_leaf && (cur & REF_SPH);
+            D.at_tri = D.at_leaf && !(cur & REF_SPH);
             D.i = cur & FIRST_MASK;
             D.fast = true;
             D.top = HYBRID ? S.stk.peek_hybrid(D.fast) : S.stk.peek();
@@ -1665,6 +1763,7 @@ struct rtgpu_ctx {
   int variant = 0;              // index into kVariants (refill threshold), see rtgpu_create
   int stack_lds = kStackLds;    // cap on LDS stack entries (RTGPU_STACK_LDS shrinks it for tests)
   bool no_node_cache = false;   // RTGPU_NO_NODE_CACHE=1: every node through the vector L1 (experiments)
+  int tiny6 = -1;               // RTGPU_TINY6=0/1: MODE 13 (two blocks of 768 threads per CU, six waves per SIMD) instead of 7; -1: kTiny6Default
   int rays2 = -1;               // RTGPU_RAYS2=0/1: MODE 8 (two rays per lane in lock step) instead of 7; -1: the default (kRays2Default)
   bool no_mats_cache = false;   // RTGPU_NO_MATS_CACHE=1: trees in memory read materials through L1 (experiments)
   bool no_tiny = false;         // RTGPU_NO_TINY=1: a scene that fits LDS whole still runs MODE 2 (experiments)
@@ -1702,13 +1801,18 @@ namespace {
 // code path; the threshold only changes WHEN finished lanes are refilled, never
 // what a path computes.  RTGPU_REFILL (0/20/40) selects it for experiments.
 using KernelFn = void (*)(const KParams);
-constexpr int kModes = 13;
-struct Variant { int refill; KernelFn fn[3][kModes]; };  // [plain, stats, profile][MODE 0..12 of trace_kernel]
+constexpr int kModes = 14;
+struct Variant { int refill; KernelFn fn[3][kModes]; };  // [plain, stats, profile][MODE 0..13 of trace_kernel]
+#ifdef RTGPU_QUICK_MODE  // development: ONE instantiation (resource usage of a kernel under work in seconds, not a minute)
+#define RTGPU_VARIANT_ROW(S, R) {trace_kernel<0, 20, RTGPU_QUICK_MODE>}
+#define RTGPU_VARIANT(R) {R, {RTGPU_VARIANT_ROW(0, R)}}
+#else
 #define RTGPU_VARIANT_ROW(S, R)                                                                         \
   {trace_kernel<S, R, 0>, trace_kernel<S, R, 1>, trace_kernel<S, R, 2>, trace_kernel<S, R, 3>, trace_kernel<S, R, 4>, \
    trace_kernel<S, R, 5>, trace_kernel<S, R, 6>, trace_kernel<S, R, 7>, trace_kernel<S, R, 8>, trace_kernel<S, R, 9>, \
-   trace_kernel<S, R, 10>, trace_kernel<S, R, 11>, trace_kernel<S, R, 12>}
+   trace_kernel<S, R, 10>, trace_kernel<S, R, 11>, trace_kernel<S, R, 12>, trace_kernel<S, R, 13>}
 #define RTGPU_VARIANT(R) {R, {RTGPU_VARIANT_ROW(0, R), RTGPU_VARIANT_ROW(1, R), RTGPU_VARIANT_ROW(2, R)}}
+#endif
 #ifndef RTGPU_REFILL_SMALL
 #define RTGPU_REFILL_SMALL 20
 #endif
@@ -1725,6 +1829,10 @@ constexpr int kVariantSmallTree = 1, kVariantLargeTree = 2;
 #define RTGPU_RAYS2_DEFAULT 0
 #endif
 constexpr bool kRays2Default = RTGPU_RAYS2_DEFAULT != 0;
+#ifndef RTGPU_TINY6_DEFAULT
+#define RTGPU_TINY6_DEFAULT 1
+#endif
+constexpr bool kTiny6Default = RTGPU_TINY6_DEFAULT != 0;
 #ifndef RTGPU_PAD_MIN_MB
 #define RTGPU_PAD_MIN_MB 128
 #endif
@@ -1855,6 +1963,7 @@ extern "C" int rtgpu_create(rtgpu_ctx **out, int device_index) {
   if (const char *env = std::getenv("RTGPU_NO_SPHERE_CACHE")) ctx->no_sphere_cache = std::atoi(env) != 0;
   if (const char *env = std::getenv("RTGPU_NO_TINY")) ctx->no_tiny = std::atoi(env) != 0;
   if (const char *env = std::getenv("RTGPU_RAYS2")) ctx->rays2 = std::atoi(env) != 0 ? 1 : 0;
+  if (const char *env = std::getenv("RTGPU_TINY6")) ctx->tiny6 = std::atoi(env) != 0 ? 1 : 0;
   if (const char *env = std::getenv("RTGPU_NODE4_PAD")) ctx->pad_nodes4 = std::atoi(env) != 0 ? 1 : 0;
   if (const char *env = std::getenv("RTGPU_SLOT_TREE")) ctx->slot_tree = std::atoi(env) != 0 ? 1 : 0;
   if (const char *env = std::getenv("RTGPU_NO_MATS_CACHE")) ctx->no_mats_cache = std::atoi(env) != 0;
@@ -1874,8 +1983,9 @@ extern "C" int rtgpu_create(rtgpu_ctx **out, int device_index) {
         }
   ctx->blocks_per_cu[0] = ctx->blocks_per_cu[1] = kBlocksPerCU;
   // (threads per CU: the larger of the two launch shapes)
-  const size_t cu_threads = (size_t)kBlocksPerCU * kBlock > (size_t)kSlotBlocksPerCU * kBlockSlots ? (size_t)kBlocksPerCU * kBlock
-                                                                                                 : (size_t)kSlotBlocksPerCU * kBlockSlots;
+  size_t cu_threads = (size_t)kBlocksPerCU * kBlock > (size_t)kSlotBlocksPerCU * kBlockSlots ? (size_t)kBlocksPerCU * kBlock
+                                                                                           : (size_t)kSlotBlocksPerCU * kBlockSlots;
+  if (cu_threads < 2u * kBlock6) cu_threads = 2u * kBlock6;  // MODE 13
   ctx->ovf_threads = (size_t)ctx->num_cus * cu_threads;
   if ((e = hipMalloc((void **)&ctx->d_wave_times, (size_t)ctx->num_cus * (cu_threads / 64) * 4 * 8)) != hipSuccess) {
     rtgpu::set_global_error(std::string("rtgpu_create: ") + hipGetErrorString(e));
@@ -2436,10 +2546,19 @@ int launch_frame(rtgpu_ctx *ctx, const rtgpu_camera *cam, const rtgpu_settings *
         mode = 8;
         lds_bytes = stack_bytes2 + (size_t)kTinyEnd * 16;
       }
+      // the scene twice per CU, six waves per SIMD (MODE 13): two blocks of kBlock6 threads, 16-bit stack entries and
+      // references (the first primitive of a leaf below 2048: kTinySphs and kTinyTris are)
+      const bool tiny6 = ctx->tiny6 >= 0 ? ctx->tiny6 != 0 : kTiny6Default;
+      const size_t stack_bytes6 = (size_t)stack_lds * kBlock6 * sizeof(uint16_t);
+      static_assert(kTinySphs < 2048 && kTinyTris < 2048 && kTinyNodes < 32768, "MODE 13: 16-bit references");
+      if (mode == 7 && tiny6 && stack_bytes6 + (size_t)kTinyEnd6 * 16 <= (size_t)kLdsBytes6) {
+        mode = 13;
+        lds_bytes = stack_bytes6 + (size_t)kTinyEnd6 * 16;
+      }
     }
   }
   if (wide || ctx->d_nodes48) {  // never a MODE 2 tree: RTGPU_NODE48_MIN_NODES > kSmallNodes
-    if (mode == 2 || mode >= 7) { ctx->err = "internal: packed nodes on a tree that fits the LDS cache"; return 2; }
+    if (mode == 2 || mode == 7 || mode == 8 || mode == 13) { ctx->err = "internal: packed nodes on a tree that fits the LDS cache"; return 2; }
     mode += wide ? 5 : 3;
   }
   if (slots) mode += 6;  // 5 -> 11, 6 -> 12
@@ -2472,7 +2591,7 @@ int launch_frame(rtgpu_ctx *ctx, const rtgpu_camera *cam, const rtgpu_settings *
     P.n_cached = (uint32_t)(ctx->host.n_nodes4 < (uint64_t)kWideCached ? ctx->host.n_nodes4 : (uint64_t)kWideCached);
     lds_bytes = stack_bytes + (size_t)kWideCached * sizeof(rtgpu_node4);
   }
-  if (mode != 2 && mode != 7 && mode != 8 && !ctx->no_mats_cache && ctx->host.n_materials > 0 &&
+  if (mode != 2 && mode != 7 && mode != 8 && mode != 13 && !ctx->no_mats_cache && ctx->host.n_materials > 0 &&
       ctx->host.n_materials <= (uint64_t)kLdsMats && kBlocksPerCU == 1) {
     const size_t mb = (size_t)ctx->host.n_materials * sizeof(rtgpu_material);
     while (lds_bytes + mb > lds_budget && !P.stack_lds_only && sc.may_allocate && P.stack_lds > 8u) {
@@ -2491,16 +2610,18 @@ int launch_frame(rtgpu_ctx *ctx, const rtgpu_camera *cam, const rtgpu_settings *
   ctx->timed = false;
   if (n_items > 0) {
     const int inst = (s->flags & RTGPU_FLAG_PROFILE) ? 2 : want_stats ? 1 : 0;
-    const unsigned block = mode == 8 ? (unsigned)kBlock2 : block_threads;
+    const unsigned block = mode == 8 ? (unsigned)kBlock2 : mode == 13 ? (unsigned)kBlock6 : block_threads;
     const uint64_t per_block = mode == 8 ? 2ull * kBlock2 : (uint64_t)block;   // work items a block holds at a time
     uint64_t want = (n_items + per_block - 1) / per_block;
     // (slot-tree modes: five blocks of 256 threads per CU; their counting and profile variants need more registers: four)
-    const uint64_t per_cu = slots ? (uint64_t)(inst == 0 ? kSlotBlocksPerCU : kSlotBlocksPerCU - 1) : (uint64_t)ctx->blocks_per_cu[want_stats ? 1 : 0];
+    // (MODE 13: two blocks of 768 threads per CU; its counting and profile variants have the registers of three waves per SIMD: one)
+    const uint64_t per_cu = slots ? (uint64_t)(inst == 0 ? kSlotBlocksPerCU : kSlotBlocksPerCU - 1)
+                            : mode == 13 ? (uint64_t)(inst == 0 ? 2 : 1) : (uint64_t)ctx->blocks_per_cu[want_stats ? 1 : 0];
     uint64_t cap = (uint64_t)ctx->num_cus * per_cu;
     unsigned grid = (unsigned)(want < cap ? want : cap);
     if ((size_t)grid * block > ctx->ovf_threads) { ctx->err = "internal: grid exceeds the overflow stack"; return 2; }
     ctx->last_waves = (uint64_t)grid * (block / 64u);
-    const Variant &var = kVariants[ctx->variant >= 0 ? ctx->variant : (mode == 2 || mode == 7 || mode == 8 ? kVariantSmallTree : kVariantLargeTree)];
+    const Variant &var = kVariants[ctx->variant >= 0 ? ctx->variant : (mode == 2 || mode == 7 || mode == 8 || mode == 13 ? kVariantSmallTree : kVariantLargeTree)];
     static_assert(RTGPU_NODE48_MIN_NODES > (unsigned)kSmallNodes, "a packed tree must not fit the LDS node cache");
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
     KernelFn fn = var.fn[inst][mode];

@@ -12,11 +12,12 @@ pytestmark = pytest.mark.gpu
 # blocks of the slot-tree modes hold 24 stack entries per lane in LDS and this tree's bound is 29; mode 12 is covered in
 # tests/test_gpu_slot_tree.py - or with RTGPU_SLOT_TREE=0 the four-wide nodes the slot tree is made from)
 CASES = [
-    ({}, ((7, 8), 11)),                                             # (7 or 8: whichever the build makes the default)
+    ({}, ((7, 8, 13), 11)),                                         # (7, 8 or 13: whichever the build makes the default)
     ({"RTGPU_NO_TINY": "1"}, (2, 11)),                              # the tree in LDS, spheres behind it
     ({"RTGPU_NO_SPHERE_CACHE": "1"}, (2, 11)),                      # the tree in LDS, spheres through L1
     ({"RTGPU_RAYS2": "1"}, (8, 11)),                                # two rays per lane in lock step (scenes in LDS)
-    ({"RTGPU_RAYS2": "0"}, (7, 11)),                                # one ray per lane
+    ({"RTGPU_RAYS2": "0", "RTGPU_TINY6": "0"}, (7, 11)),            # one ray per lane, one block of 1024 threads per CU
+    ({"RTGPU_RAYS2": "0", "RTGPU_TINY6": "1"}, (13, 11)),           # ... two blocks of 768 threads, the scene in LDS twice
     ({"RTGPU_STACK_LDS": "9"}, (0, 11)),                            # nine stack entries in LDS, the rest in memory: S0's tree too
     ({"RTGPU_REFILL": "0"}, (7, 11)),                               # plain while-while traversal rounds
     ({"RTGPU_NO_MATS_CACHE": "1"}, (7, 11)),                        # trees in memory: materials through L1, not LDS
@@ -61,7 +62,7 @@ def test_experiment_switches_leave_the_frame_alone(ra, gpu_ctx, monkeypatch, env
     assert want[0][3] in CASES[0][1][0] and want[1][3] == CASES[0][1][1]
     got = _frames_with(ra, monkeypatch, env)
     if modes[0] == 7 and "RTGPU_RAYS2" not in env:
-        modes = (want[0][3], modes[1])                           # the switch leaves the choice between 7 and 8 alone
+        modes = (want[0][3], modes[1])                           # the switch leaves the choice between 7, 8 and 13 alone
     assert tuple(f[3] for f in got) == modes
     for (a, ia, sa, _), (b, ib, sb, _) in zip(got, want):
         assert_bit_equal(a, b, f"{env}")
@@ -88,3 +89,37 @@ def test_four_wide_nodes_give_the_slot_trees_frame(ra, oracle, gpu_ctx, monkeypa
     o, io, so = oracle.render(fs.c, cam, st, slot_tree=False, threads=8)
     assert_bit_equal(got[1][0], o, "oracle over the four-wide nodes")
     assert np.array_equal(got[1][1], io) and got[1][2] == so
+
+
+def test_six_waves_per_simd_product_kernel(ra, oracle, monkeypatch):
+    """Mode 13 as it ships (no statistics flag: two blocks of 768 threads per CU, 80 registers): S0 in several chunks through
+    the thin lens, against the oracle and against mode 7; then a progressive second frame on top."""
+    scene, _ = ra.Scene.builtin(0, param=0, aspect=200 / 120)
+    cam = ra.look_at((13, 2, 3), (0, 0, 0), vfov=20.0, aspect=200 / 120, aperture=0.1, focus_dist=10.0)
+    st = ra.default_settings(200, 120, spp=5, max_depth=8, seed=3)
+    st.chunk_samples = 2
+    frames = {}
+    for tiny6 in ("1", "0"):
+        monkeypatch.setenv("RTGPU_TINY6", tiny6)
+        monkeypatch.setenv("RTGPU_RAYS2", "0")
+        ctx = ra.Context(0)
+        try:
+            ctx.upload(scene)
+            a, ia, _ = ctx.render(cam, st, want_stats=False)
+            assert int(ctx.kernel_name().rstrip(">").split(",")[-1]) == (13 if tiny6 == "1" else 7)
+            assert ctx.kernel_name().startswith("trace_kernel<0,")
+            st2 = st.copy()
+            st2.flags = ra.FLAG_ACCUMULATE
+            st2.sample_offset = st.spp
+            b, _, _ = ctx.render(cam, st2, accum=a.copy(), want_ids=False, want_stats=False)
+            frames[tiny6] = (a, ia, b)
+            if tiny6 == "1":
+                fs = ctx.flat_scene()
+                o, io, _ = oracle.render(fs.c, cam, st, threads=8)
+                assert_bit_equal(a, o, "mode 13 against the oracle")
+                assert np.array_equal(ia, io)
+        finally:
+            ctx.close()
+    assert_bit_equal(frames["1"][0], frames["0"][0], "mode 13 against mode 7")
+    assert np.array_equal(frames["1"][1], frames["0"][1])
+    assert_bit_equal(frames["1"][2], frames["0"][2], "second progressive frame")

@@ -15,10 +15,11 @@ pytestmark = pytest.mark.gpu
 
 
 def _assert_mode(ctx, mode):
-    """The kernel mode of the last launch.  Where a scene fits LDS whole the build (or RTGPU_RAYS2) chooses
-    between mode 7 (one ray per lane) and mode 8 (two rays per lane in lock step): the same frame either way."""
+    """The kernel mode of the last launch.  Where a scene fits LDS whole the build (or RTGPU_RAYS2 / RTGPU_TINY6) chooses
+    between mode 7 (one block of 1024 threads per CU), mode 8 (two rays per lane in lock step) and mode 13 (two blocks of
+    768 threads per CU, each with its own copy of the scene: six waves per SIMD): the same frame every way."""
     got = int(ctx.kernel_name().rstrip(">").split(",")[-1])
-    assert got in ((7, 8) if mode == 7 else (mode,)), ctx.kernel_name()
+    assert got in ((7, 8, 13) if mode == 7 else (mode,)), ctx.kernel_name()
 
 REL_TOL_1SPP = 1e-4
 PSNR_MIN_DB = 50.0
