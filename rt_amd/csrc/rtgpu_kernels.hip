@@ -112,6 +112,20 @@ constexpr int      kSlotWaves = kBlockSlots * kSlotBlocksPerCU / 256;           
 constexpr int      kLdsSlotBytes = 160 * 1024 / kSlotBlocksPerCU - 2048;           // LDS share of one such block
 constexpr int      kLdsMats    = 64;   // trees in memory: material tables up to this size are copied to LDS (2 KiB)
 constexpr unsigned kChunk      = 64;   // work items drawn per queue atomic (one 8x8 pixel block)
+// The END of the queue is handed out in smaller draws from a second head: when the queue runs dry every wave still owns what is
+// left of its last draw, which only its own lanes can take - half a draw on average, and the launch ends when the unluckiest wave
+// has worked its share off.  How small depends on how fast the grid takes items: a returning atomic on one word saturates near 88
+// per microsecond chip-wide, so a wave sizes its draws from the time its own draws have taken so far (KParams.tail_thr*: the host
+// knows the waves of the grid).  Frames of slow items (S2: 0.6 ms per item and lane) end on draws of 16, frames of fast ones (S0,
+// S1: 0.16 ms) keep 64 - for them small draws measured SLOWER (C2 +4 %, C3 +1 %), for C5's frame 3.9 % faster.
+#ifndef RTGPU_TAIL_ATOMICS_PER_US   // the atomic rate the tail draws of the whole grid may add up to
+#define RTGPU_TAIL_ATOMICS_PER_US 60
+#endif
+#ifndef RTGPU_TAIL_ITEMS_PER_LANE_X4   // length of that end of the queue: this many quarters of an item per lane of the grid
+#define RTGPU_TAIL_ITEMS_PER_LANE_X4 4
+#endif
+constexpr unsigned kTailHead   = 31;   // counters[] word of the second head
+
 constexpr float    kTMax       = 3.402823466e+38f;  // FLT_MAX: initial closest-hit distance
 
 struct KParams {
@@ -131,6 +145,9 @@ struct KParams {
   float sky_bottom[3], sky_top[3];
   uint32_t width, height, spp, sample_offset, max_depth, seed;
   uint32_t ts_log2, tiles_x, rank, world, n_items, flags;
+  // items [0, n_big) are drawn kChunk at a time from counters[0], the rest from counters[kTailHead] 16, 32 or 64 at a time: 32 (16)
+  // by a wave that has taken at least tail_thr32 (tail_thr16) ticks of 10 ns per draw so far
+  uint32_t n_big, tail_thr32, tail_thr16;
   uint32_t stack_lds, stack_lds_only;
   uint32_t n_cached;  // nodes [0, n_cached) are read from the LDS copy
   uint32_t sph_cached; // MODE 2, 7: > 0 = the leaf-ordered spheres (this many: all of them) sit in LDS behind the node planes
@@ -595,6 +612,10 @@ void trace_kernel(const KParams P) {
   // wave-uniform description of the group the pool was drawn from (see (2))
   uint32_t g_px = 0, g_py = 0, g_out = 0, g_row = 0, g_chunk = 0, g_sample = 0, g_sample_end = 0;
   bool queue_dry = false;                // wave-uniform: the global head has passed n_items
+  unsigned tail_draw = 0;                // wave-uniform: 0 while the wave draws from the first head, then its draw size at the second
+  unsigned g_end = 0;                    // wave-uniform: end of the part of the pool that g_* describes (a pool may cross into the next 8x8 block)
+  unsigned n_draws = 0;                  // wave-uniform: draws from the first head so far
+  const uint32_t t_begin = (uint32_t)__builtin_amdgcn_s_memrealtime();  // 100 MHz
   // LDS copy of the n_cached nodes nearest the root (the builder numbers them
   // breadth-first), as four planes [16-byte quarter][node]: lanes of a wave read
   // quarter j of DIFFERENT nodes, and in this layout consecutive nodes sit in
@@ -899,20 +920,35 @@ void trace_kernel(const KParams P) {
     // by their rank among the needy lanes (ballot + mbcnt prefix); when the group
     // runs out mid-wave the loop below goes round once more with a fresh group.
     unsigned long long need_mask = __ballot(need_pixel);
-    while (need_mask != 0ull) {  // wave-uniform, at most two rounds
-      if (pool_next == pool_end) {  // wave-uniform: draw the next group
+    while (need_mask != 0ull) {  // wave-uniform: every round hands out items or ends the loop
+      if (pool_next == g_end) {  // wave-uniform: the next 8x8 block of the pool, after the next draw if the pool is empty
         KArgs K = kargs();
         const uint32_t ts = 1u << K->ts_log2;
         const uint32_t blocks_per_row_log2 = K->ts_log2 - 3u;  // 8x8 pixel blocks per tile row
         // once a wave has seen the queue dry it never asks again: thousands of
         // waves polling a dry head with one atomic per iteration saturate the
         // atomic unit and stretch the tail of the launch
-        unsigned nb = K->n_items;
+        if (pool_next == pool_end) {
+        unsigned nb = K->n_items, draw = kChunk;
         if (!queue_dry) {
           const unsigned leader = (unsigned)__ffsll((long long)need_mask) - 1u;
-          unsigned long long fetched = 0ull;
-          if (lane == leader) fetched = atomicAdd(&K->counters[0], (unsigned long long)kChunk);
-          fetched = __shfl(fetched, (int)leader, 64);
+          unsigned long long fetched = ~0ull;
+          if (tail_draw == 0u) {
+            if (lane == leader) fetched = atomicAdd(&K->counters[0], (unsigned long long)kChunk);
+            fetched = __shfl(fetched, (int)leader, 64);
+            if (__builtin_amdgcn_readfirstlane((int)(fetched >= (unsigned long long)K->n_big)) != 0) {
+              // the first head has passed n_big: from here on the second head, in draws sized by this wave's time per draw so far
+              const float dt = (float)((uint32_t)__builtin_amdgcn_s_memrealtime() - t_begin), n = (float)n_draws;
+              const bool d16 = dt >= (float)K->tail_thr16 * n, d32 = dt >= (float)K->tail_thr32 * n;
+              tail_draw = (unsigned)__builtin_amdgcn_readfirstlane(d16 ? 16 : d32 ? 32 : 64);
+            }
+            n_draws++;
+          }
+          if (tail_draw != 0u) {  // (also in the iteration that found the first head past n_big)
+            if (lane == leader) fetched = atomicAdd(&K->counters[kTailHead], (unsigned long long)tail_draw);
+            fetched = __shfl(fetched, (int)leader, 64) + (unsigned long long)K->n_big;
+            draw = tail_draw;
+          }
           // a head beyond n_items means the queue is dry; clamp so u32 math cannot wrap
           nb = fetched >= (unsigned long long)K->n_items ? K->n_items : (unsigned)fetched;
           nb = (unsigned)__builtin_amdgcn_readfirstlane((int)nb);
@@ -924,9 +960,13 @@ void trace_kernel(const KParams P) {
           break;
         }
         pool_next = nb;
-        pool_end = nb + kChunk;  // n_items is a multiple of kChunk
+        // (n_items and n_big are multiples of kChunk; draws of different sizes share the second head, so a draw may start
+        // anywhere on a multiple of 16, cross into the next 8x8 block and reach past the end of the queue)
+        pool_end = nb + draw < K->n_items ? nb + draw : K->n_items;
+        }
+        g_end = (pool_next | 63u) + 1u < pool_end ? (pool_next | 63u) + 1u : pool_end;
         // group -> (64-pixel group, chunk of samples): groups x chunks, pixel-group-major
-        uint32_t grp = nb >> 6, pix_grp = grp, chunk_u = 0u;
+        uint32_t grp = pool_next >> 6, pix_grp = grp, chunk_u = 0u;
         if (K->n_chunks > 1u) {
           if (K->groups_small) {  // float estimate, exact below 2^22, corrected by at most one
             pix_grp = (uint32_t)((float)grp * K->inv_n_chunks);
@@ -971,7 +1011,7 @@ void trace_kernel(const KParams P) {
       const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(need_mask >> 32),
                                                       __builtin_amdgcn_mbcnt_lo((unsigned)need_mask, 0u));
       const unsigned cnt = (unsigned)__builtin_popcountll(need_mask);
-      const unsigned avail = pool_end - pool_next;  // wave-uniform, >= 1
+      const unsigned avail = g_end - pool_next;  // wave-uniform, >= 1
       if (need_pixel && rank < avail) {
         const uint32_t within = (pool_next + rank) & 63u, wx = within & 7u, wy = within >> 3;
         const uint32_t px = g_px + wx, py = g_py + wy;
@@ -2405,7 +2445,7 @@ int launch_frame(rtgpu_ctx *ctx, const rtgpu_camera *cam, const rtgpu_settings *
   const uint32_t n_rounds = (n_chunks + kRoundChunks - 1) / kRoundChunks;
   const uint32_t n_planes = n_chunks > 1 ? round_chunks + (n_rounds > 1 ? 1u : 0u) : 0u;
   uint64_t n_items = n_px_items * round_chunks;  // of the largest round
-  if (n_items >= 0xFFFFFFFFull) { ctx->err = "frame too large for one launch (>= 2^32 work items)"; return 1; }
+  if (n_items >= 0xFFFFFF00ull) { ctx->err = "frame too large for one launch (>= 2^32 - 256 work items)"; return 1; }
   uint64_t n_px_out = (s->flags & RTGPU_FLAG_COMPACT) ? n_px_items : (uint64_t)s->width * s->height;
   float4 *planes = sc.planes;
   if (n_chunks > 1 && n_px_out > 0 && !sc.may_allocate) {
@@ -2493,6 +2533,7 @@ int launch_frame(rtgpu_ctx *ctx, const rtgpu_camera *cam, const rtgpu_settings *
   P.max_depth = s->max_depth; P.seed = s->seed;
   P.ts_log2 = ts_log2; P.tiles_x = g.tiles_x; P.rank = s->rank; P.world = s->world_size;
   P.n_items = (uint32_t)n_items; P.flags = s->flags;
+  P.n_big = (uint32_t)n_items;  // (set below, once the grid is known)
   P.planes = planes;
   P.chunk_samples = s->chunk_samples; P.n_chunks = round_chunks; P.plane_stride = (uint32_t)n_px_out;
   P.groups_small = (n_items >> 6) < (1ull << 22) ? 1u : 0u;
@@ -2621,6 +2662,22 @@ int launch_frame(rtgpu_ctx *ctx, const rtgpu_camera *cam, const rtgpu_settings *
     unsigned grid = (unsigned)(want < cap ? want : cap);
     if ((size_t)grid * block > ctx->ovf_threads) { ctx->err = "internal: grid exceeds the overflow stack"; return 2; }
     ctx->last_waves = (uint64_t)grid * (block / 64u);
+    // the end of the queue in small draws: a quarter of an item per lane of the grid x RTGPU_TAIL_ITEMS_PER_LANE_X4
+    auto n_big_of = [&](uint64_t items, unsigned grid_) {
+      const uint64_t tail = ((uint64_t)grid_ * block * RTGPU_TAIL_ITEMS_PER_LANE_X4 / 4u + 63u) & ~63ull;
+      return (uint32_t)(items > tail ? items - tail : 0u);
+    };
+    P.n_big = n_big_of(n_items, grid);
+    {  // ticks of 10 ns per draw of 64 from which the grid's draws of 32 (16) stay below RTGPU_TAIL_ATOMICS_PER_US
+      const double waves = (double)grid * (block / 64u);
+      P.tail_thr32 = (uint32_t)(100.0 * waves * 2.0 / RTGPU_TAIL_ATOMICS_PER_US);
+      P.tail_thr16 = (uint32_t)(100.0 * waves * 4.0 / RTGPU_TAIL_ATOMICS_PER_US);
+      if (const char *env = std::getenv("RTGPU_TAIL_DRAW")) {  // experiments: 16 / 32 / 64 for every wave
+        const int d = std::atoi(env);
+        P.tail_thr16 = d == 16 ? 0u : 0xFFFFFFFFu;
+        P.tail_thr32 = d == 16 || d == 32 ? 0u : 0xFFFFFFFFu;
+      }
+    }
     const Variant &var = kVariants[ctx->variant >= 0 ? ctx->variant : (mode == 2 || mode == 7 || mode == 8 || mode == 13 ? kVariantSmallTree : kVariantLargeTree)];
     static_assert(RTGPU_NODE48_MIN_NODES > (unsigned)kSmallNodes, "a packed tree must not fit the LDS node cache");
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
@@ -2643,10 +2700,14 @@ int launch_frame(rtgpu_ctx *ctx, const rtgpu_camera *cam, const rtgpu_settings *
         P.spp = s->spp - first_chunk * s->chunk_samples;
         P.n_chunks = chunks_r; P.inv_n_chunks = 1.0f / (float)chunks_r;
         P.n_items = (uint32_t)items_r;
+        P.n_big = n_big_of(items_r, (unsigned)(want_r < cap ? want_r : cap));
         P.groups_small = (items_r >> 6) < (1ull << 22) ? 1u : 0u;
         if (r > 0) P.prim_id = nullptr;
         grid_r = (unsigned)(want_r < cap ? want_r : cap);
-        if (r > 0) HIP_TRY(ctx, hipMemsetAsync(sc.counters, 0, sizeof(unsigned long long), stream));
+        if (r > 0) {
+          HIP_TRY(ctx, hipMemsetAsync(sc.counters, 0, sizeof(unsigned long long), stream));
+          HIP_TRY(ctx, hipMemsetAsync(sc.counters + kTailHead, 0, sizeof(unsigned long long), stream));
+        }
       }
       hipLaunchKernelGGL(fn, dim3(grid_r), dim3(block), lds_bytes, stream, P);
       HIP_TRY(ctx, hipGetLastError());
