@@ -121,6 +121,9 @@ constexpr unsigned kChunk      = 64;   // work items drawn per queue atomic (one
 #ifndef RTGPU_TAIL_ATOMICS_PER_US   // the atomic rate the tail draws of the whole grid may add up to
 #define RTGPU_TAIL_ATOMICS_PER_US 60
 #endif
+#ifndef RTGPU_TAIL_SHARE   // 0: no sample sharing at the end of the launch (experiments)
+#define RTGPU_TAIL_SHARE 1
+#endif
 #ifndef RTGPU_TAIL_ITEMS_PER_LANE_X4   // length of that end of the queue: this many quarters of an item per lane of the grid
 #define RTGPU_TAIL_ITEMS_PER_LANE_X4 4
 #endif
@@ -491,6 +494,12 @@ void trace_kernel(const KParams P) {
   constexpr uint32_t CNT_SHIFT = T6 ? 11u : SLOTS ? 28u : 27u, CNT_MASK = SLOTS ? 3u : 7u, FIRST_MASK = (1u << CNT_SHIFT) - 1u,
                      REF_SPH = T6 ? (1u << 14) : RTGPU_REF_SPHERE;
   constexpr int R = MODE == 8 ? 2 : 1;                  // rays a lane traverses in lock step
+  // (2b) below: at the end of the launch idle lanes trace later samples of their wave's unfinished items.  The item's chunk
+  // shares its register with that bookkeeping: chunk (of the round: below 64) | samples lent << 16 | helper flags
+  // Trees in memory only: C5's frame -3.5 %, S2 level 8 at 4 spp -3.5 %, C3 unchanged; for the scenes in LDS the handful of
+  // instructions it adds to every outer iteration cost more (C4's frame +1.5 %) than the shorter tail returns (C2 +-0).
+  constexpr bool SHARE = R == 1 && !SMALL && RTGPU_TAIL_SHARE != 0;
+  constexpr uint32_t kLentShift = 16u, kHelping = 1u << 24, kFresh = 1u << 25, kPending = 1u << 26;
   constexpr int BLOCK = MODE == 8 ? kBlock2 : T6 ? kBlock6 : SLOTS ? kBlockSlots : kBlock;   // threads per block
   constexpr int STRIDE = BLOCK * R;                     // words between consecutive entries of one stack
 #ifdef RTGPU_NO_HIT_NORMAL  // experiments: shading fetches the triangle again
@@ -603,6 +612,9 @@ void trace_kernel(const KParams P) {
     S.stk.lds_entries = (int)P.stack_lds;
     S.stk.base_at[0] = (StackEntry)kDone;  // sentinel under every stack (never overwritten)
   };
+  // MODE 13: LDS address of the first stack entry of this wave's lane 0 (wave-uniform)
+  const uint32_t stack_wave_at = (uint32_t)__builtin_amdgcn_readfirstlane(
+      (int)(uint32_t)(uintptr_t)((typename StackT::lds_u32 *)smem + (tid & ~63u)));
   init_ray(ray0, 0);
   init_ray(ray1, R - 1);  // (R == 1: the same words again; ray1 is then never used)
   unsigned long long n_paths = 0, n_rays = 0, n_nodes = 0, n_tris = 0, n_sphs = 0, n_scat = 0;
@@ -738,6 +750,8 @@ void trace_kernel(const KParams P) {
     if (STATS == 2) { wave_tick(lane, w_outer); if (queue_dry) n_after_dry++; }
     // sections (1)-(3) for one ray of the lane; true if the ray is in flight afterwards
     auto outer_sections = [&](Ray &S) __attribute__((always_inline)) {
+    constexpr bool TSHARE = SHARE;
+    constexpr uint32_t kChunkMask = TSHARE ? 0xFFFFu : 0xFFFFFFFFu;
     // ---- (1) shade the rays whose traversal has finished (rows a6, a8) ----------
     if (S.alive && S.cur == kDone) {
       if (STATS == 2) { wave_tick(lane, w_shade); l_shade++; }
@@ -886,16 +900,17 @@ void trace_kernel(const KParams P) {
     auto sample_end_of = [&](const Ray &S_) __attribute__((always_inline)) {
       if (!DIET) return S_.sample_end;
       KArgs K = kargs();
-      const uint32_t e = (S_.chunk + 1u) * K->chunk_samples;
+      const uint32_t e = ((S_.chunk & kChunkMask) + 1u) * K->chunk_samples;
       return e < K->spp ? e : K->spp;
     };
+    if (TSHARE && queue_dry) S.chunk &= ~kPending;
     bool need_pixel = !S.alive && !S.done && (!S.have_pixel || S.sample >= sample_end_of(S));
     if (need_pixel && S.have_pixel) {
       if (S.pixel_valid) {
         KArgs K = kargs();
         const V3 sum = SUM_LDS ? mk(lds_sum[0], lds_sum[BLOCK], lds_sum[2 * BLOCK]) : S.sum;
         if (K->n_chunks > 1u) {
-          K->planes[(size_t)S.chunk * K->plane_stride + S.out_index] = make_float4(sum.x, sum.y, sum.z, 0.0f);
+          K->planes[(size_t)(S.chunk & kChunkMask) * K->plane_stride + S.out_index] = make_float4(sum.x, sum.y, sum.z, 0.0f);
         } else {
           float4 o = make_float4(sum.x, sum.y, sum.z, (float)K->spp);
           if (K->flags & RTGPU_FLAG_ACCUMULATE) {
@@ -904,7 +919,7 @@ void trace_kernel(const KParams P) {
           }
           K->accum[S.out_index] = o;
         }
-        if (!DIET && K->prim_id && S.chunk == 0u) K->prim_id[S.out_index] = S.first_id;
+        if (!DIET && K->prim_id && (S.chunk & kChunkMask) == 0u) K->prim_id[S.out_index] = S.first_id;
       }
       S.have_pixel = false;
     }
@@ -1031,8 +1046,81 @@ void trace_kernel(const KParams P) {
       pool_next += cnt < avail ? cnt : avail;
       need_mask = __ballot(need_pixel);
     }
+    // ---- (2b) the end of the launch: idle lanes trace LATER SAMPLES of their wave's unfinished items ----
+    // Once the queue is dry a lane that finishes its item has nothing left to take, and the wave lasts as long as its slowest
+    // item - up to chunk_samples paths one after the other (measured on C2: 54 outer iterations after the queue ran dry at
+    // the median, of 15 per item on average; a fifth of the launch with ever fewer lanes at work).  The samples of an item are
+    // independent paths; only their SUM has an order.  So an idle lane (the helper) takes one later sample of another lane's
+    // item (the owner): pixel and sample index are all a path's random stream is keyed on.  It traces it into a sum of its own
+    // that starts at zero, and the owner adds that sum where the sample's own radiance would have been added: when every
+    // sample before it has been added.  0 + L == L bit for bit (and a sum is never -0), so the frame is the same frame.
+    // Everything stays inside the wave: lanes find each other with ballots and v_readlane; no memory, no other wave.
+    if (TSHARE && queue_dry) {
+      const bool helping = (S.chunk & kHelping) != 0u;
+      // (i) finished helpers hand over, in lane order; an owner takes a sample only when it is the next of its item
+      unsigned long long hold = __ballot(helping && !S.alive && !(S.chunk & kFresh));
+      while (hold != 0ull) {  // wave-uniform
+        const int h = __builtin_ctzll(hold);
+        hold &= hold - 1ull;
+        const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)S.out_index, h);             // the owner's lane
+        const uint32_t j = (uint32_t)__builtin_amdgcn_readlane((int)S.sample, h) - 1u;            // the sample it traced
+        V3 part;
+        if (SUM_LDS) {
+          const int d = h - (int)lane;  // the helper's words, seen from this lane's
+          part = mk(lds_sum[d], lds_sum[BLOCK + d], lds_sum[2 * BLOCK + d]);
+        } else {
+          part = mk(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, S.sum.x), h)),
+                    __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, S.sum.y), h)),
+                    __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, S.sum.z), h)));
+        }
+        const bool take = lane == o && !S.alive && !helping && S.sample == j;
+        if (take) {
+          if (SUM_LDS) { lds_sum[0] = lds_sum[0] + part.x; lds_sum[BLOCK] = lds_sum[BLOCK] + part.y; lds_sum[2 * BLOCK] = lds_sum[2 * BLOCK] + part.z; }
+          else S.sum = S.sum + part;
+          S.sample++;
+          S.chunk -= 1u << kLentShift;
+          S.chunk |= kPending;  // (keeps the wave going until the top of (2) has seen the item, which may be complete now)
+        }
+        if (__ballot(take) != 0ull && lane == (unsigned)h) S.chunk = 0u;  // the helper is idle again
+      }
+      // (that may have completed an item: its lane writes it out in the next iteration - there is one: kPending)
+      // (ii) idle lanes take the next samples nobody traces yet, one owner after the other so that they spread
+      unsigned long long idle = __ballot(S.done && !(S.chunk & kHelping));
+      if (idle != 0ull) {
+        for (;;) {  // wave-uniform
+          const uint32_t lent = (S.chunk >> kLentShift) & 0xFFu;
+          const uint32_t next = S.sample + lent + (S.alive ? 1u : 0u);  // (an owner that waits has lent S.sample itself)
+          const bool can_lend = !S.done && S.have_pixel && S.pixel_valid && (S.alive || lent != 0u) && lent < 255u &&
+                                next < sample_end_of(S);
+          unsigned long long own = __ballot(can_lend);
+          if (own == 0ull) break;
+          while (own != 0ull && idle != 0ull) {
+            const int o = __builtin_ctzll(own), h = __builtin_ctzll(idle);
+            own &= own - 1ull;
+            idle &= idle - 1ull;
+            const uint32_t px_o = (uint32_t)__builtin_amdgcn_readlane((int)S.px, o), py_o = (uint32_t)__builtin_amdgcn_readlane((int)S.py, o);
+            const uint32_t smp = (uint32_t)__builtin_amdgcn_readlane((int)next, o);
+            if (lane == (unsigned)h) {
+              S.px = px_o; S.py = py_o; S.sample = smp;
+              S.out_index = (uint32_t)o;
+              S.chunk = kHelping | kFresh;
+              S.have_pixel = false;
+              if (SUM_LDS) { lds_sum[0] = 0.f; lds_sum[BLOCK] = 0.f; lds_sum[2 * BLOCK] = 0.f; }
+              else S.sum = mk(0.f, 0.f, 0.f);
+            }
+            if (lane == (unsigned)o) S.chunk += 1u << kLentShift;
+          }
+          if (idle == 0ull) break;
+        }
+      }
+    }
     SECTION_END(c_item);
-    if (!S.alive && !S.done && S.have_pixel && S.sample < sample_end_of(S)) {
+    // (TSHARE: not a sample that a helper has - one compare: any of the bits above the chunk says no, and the only such bit a
+    // lane with an item of its own can have besides its count of lent samples is kPending, cleared at the top of (2))
+    const bool own_next = !S.alive && !S.done && S.have_pixel && S.sample < sample_end_of(S) &&
+                          (!TSHARE || S.chunk <= kChunkMask);
+    if (own_next || (TSHARE && queue_dry && !S.alive && (S.chunk & kFresh))) {
+      if (TSHARE && queue_dry) S.chunk &= ~kFresh;
       // ---- camera ray (row a1) ----
       if (STATS == 2) wave_tick(lane, w_gen);
       KArgs K = kargs();
@@ -1089,11 +1177,21 @@ void trace_kernel(const KParams P) {
       S.tbest = kTMax;
       S.hit_ref = kDone;
       S.cur = 0;  // root
-      S.stk.reset();
+      if (T6) {
+        // the stack's first entry from the wave's (uniform) offset and the lane, not from a register kept across the loop:
+        // this kernel has none to spare (the empty asm keeps the sum from being hoisted out of the loop)
+        uint32_t wave_at = stack_wave_at;
+        asm volatile("" : "+s"(wave_at));
+        S.stk.top_at = (typename StackT::lds_u32 *)(uintptr_t)(wave_at + lane * (uint32_t)sizeof(StackEntry));
+      } else {
+        S.stk.reset();
+      }
       n_rays++;
     }
     SECTION_END(c_setup);
-    return S.alive;
+    // (SHARE: a helper that holds a finished sample, an owner that waits for one, and an item that a handed-over sample has
+    // just completed - it is written out at the top of (2) - keep the wave going)
+    return S.alive || (TSHARE && S.chunk > kChunkMask);
     };
     bool any_alive = outer_sections(ray0);
     if (R == 2) any_alive = outer_sections(ray1) || any_alive;

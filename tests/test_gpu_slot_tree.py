@@ -196,3 +196,30 @@ def test_tree_without_a_slot_form_runs_on_the_four_wide_nodes(ra, oracle, gpu_ct
     b, ib, sb = oracle.render(fs.c, cam, st, threads=8)
     assert_bit_equal(a, b, "no slot form")
     assert np.array_equal(ia, ib) and sa.as_dict() == sb and (ia != 0xFFFFFFFF).sum() > 100
+
+
+@pytest.mark.parametrize("spp,chunk", [(12, 12), (7, 3), (33, 16)])
+def test_idle_lanes_trace_later_samples_at_the_end_of_the_launch(ra, oracle, gpu_ctx, spp, chunk):
+    """Once the queue is dry idle lanes take later samples of their wave's unfinished items (trace loop, section 2b) and the
+    owner adds their sums in sample order: the frame, the ids and the counters are the oracle's.  Small frames of long items
+    (a wave's whole life is the end of the launch), glass and metal in the scene (long paths), with and without statistics,
+    and a progressive second frame on top."""
+    scene, cam = ra.Scene.builtin(2, param=4, aspect=1.5)
+    st = ra.default_settings(72, 48, spp=spp, max_depth=8, seed=5, flags=ra.FLAG_STATS)
+    st.chunk_samples = chunk
+    gpu_ctx.upload(scene)
+    a, ia, sa = gpu_ctx.render(cam, st)
+    assert _mode(gpu_ctx) in (11, 12)
+    b, ib, sb = oracle.render(gpu_ctx.flat_scene().c, cam, st, threads=8)
+    assert_bit_equal(a, b, "long items")
+    assert np.array_equal(ia, ib) and sa.as_dict() == sb
+    st.flags = 0
+    a2, ia2, _ = gpu_ctx.render(cam, st, want_stats=False)
+    assert_bit_equal(a2, a, "product kernel against its counting variant")
+    assert np.array_equal(ia2, ia)
+    st.flags = ra.FLAG_ACCUMULATE
+    st.sample_offset = spp
+    a3, _, _ = gpu_ctx.render(cam, st, accum=a2.copy(), want_ids=False, want_stats=False)
+    st.flags = ra.FLAG_ACCUMULATE | ra.FLAG_STATS
+    b3, _, _ = oracle.render(gpu_ctx.flat_scene().c, cam, st, accum=b.copy(), threads=8)
+    assert_bit_equal(a3, b3, "second progressive frame")
