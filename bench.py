@@ -132,7 +132,7 @@ def roofline_block(bound, counts, n_px, node_bytes, k_ms, kernel, pmc, ub, in_me
                         "vector L1 (16 B per lane and load; ~0.7 cycle per lane-load), at the rate of tables that fit one L2.  frac = time "
                         "the launch's record fetches need at that rate / kernel time.  The HBM fraction above is what the contract's "
                         "`bound` asks for; this and valu_issue are the two ceilings the kernel runs under, neither saturated: what is "
-                        "left is latency that four waves per SIMD do not cover (DESIGN.md §5.2)."}
+                        "left is latency that five waves per SIMD do not cover (DESIGN.md §5.2)."}
     out = {"bound": bound, "traffic": traffic, "traffic_source": pmc.get("source") if pmc else None,
            "kernel": kernel, "kernel_ms": round(k_ms, 4),
            "kernel_mrays_per_s": round(counts["rays"] / sec / 1e6, 1), "valu": valu, "hbm": hbm, "vmem": vmem}

@@ -28,8 +28,15 @@ for name, kind, param, w, h, spp in CASES:
         same = (np.array_equal(ids, want_ids) and np.array_equal(acc.view(np.uint32), want.view(np.uint32))
                 and stats.as_dict() == want_stats)
         ok &= same
-        print(f"{name} {builder}: {w}x{h} {spp} spp, {len(scene.triangles) + len(scene.spheres)} prims, {ctx.kernel_name()}, "
-              f"{stats.rays} rays: {'bit-identical, counters equal' if same else 'MISMATCH'} (oracle {dt:.1f} s)", flush=True)
+        counting = ctx.kernel_name()
+        # the product kernel (no statistics flag: its own instantiation, registers and launch shape) gives the same frame
+        st.flags = 0
+        acc2, ids2, _ = ctx.render(cam, st, want_stats=False)
+        same2 = np.array_equal(ids2, ids) and np.array_equal(acc2.view(np.uint32), acc.view(np.uint32))
+        ok &= same2
+        print(f"{name} {builder}: {w}x{h} {spp} spp, {len(scene.triangles) + len(scene.spheres)} prims, {counting}, "
+              f"{stats.rays} rays: {'bit-identical, counters equal' if same else 'MISMATCH'} (oracle {dt:.1f} s); "
+              f"{ctx.kernel_name()}: {'the same frame' if same2 else 'MISMATCH'}", flush=True)
 print("FULL PARITY", "OK" if ok else "FAIL", flush=True)
 ctx.close()
 sys.exit(0 if ok else 1)
