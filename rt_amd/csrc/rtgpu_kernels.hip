@@ -88,7 +88,8 @@ constexpr int      kTinyNodes = 512, kTinySphs = 496, kTinyTris = 16;
 constexpr int      kTinySphAt = 4 * kTinyNodes, kTinyTriAt = kTinySphAt + kTinySphs, kTinyTriNAt = kTinyTriAt + 3 * kTinyTris,
                    kTinySphMatAt = kTinyTriNAt + kTinyTris, kTinyTriMatAt = kTinySphMatAt + 2 * kTinySphs,
                    kTinyMetaAt = kTinyTriMatAt + 2 * kTinyTris, kTinyEnd = kTinyMetaAt + kTinySphs / 2;
-constexpr int      kTinySphAt6 = 3 * kTinyNodes + kTinyNodes / 2, kTinyEnd6 = kTinyEnd - kTinyNodes / 2;  // MODE 13: 8-byte fourth plane
+// MODE 13: three node planes (the child references, 8 bytes per node, sit at the start of the block's LDS: kTinyRefBytes)
+constexpr int      kTinySphAt6 = 3 * kTinyNodes, kTinyEnd6 = kTinyEnd - kTinyNodes, kTinyRefBytes = kTinyNodes * 8;
 static_assert(kTinyEnd * 16 <= 65536, "MODE 7: every array within reach of a 16-bit ds_read offset");
 // MODE 5 of the trace kernel: the first kWideCached four-wide nodes (the top of the tree: both
 // collapses number it breadth first) live in LDS as six 16-byte planes this many nodes apart
@@ -524,7 +525,11 @@ void trace_kernel(const KParams P) {
   // fifth wave per SIMD
   constexpr bool SUM_LDS = SLOTS, DIET = SLOTS || T6;
   typedef __attribute__((address_space(3))) float lds_f32;
-  const uint32_t stack_words = T6 ? P.stack_lds * (STRIDE / 2) : P.stack_lds * STRIDE;  // MODE 13: 16-bit entries
+  // MODE 13: [child references: kTinyNodes x 8 B][stacks of 16-bit entries][three node planes, spheres, ...].  The references sit
+  // at the very start of the block's LDS and an inner node's reference IS the byte offset of its pair there (node x 8): the
+  // ds_read of the pair needs no address arithmetic, the node planes one v_lshl_add (offset x 2 + base of the planes)
+  constexpr uint32_t kRefWords = T6 ? (uint32_t)kTinyNodes * 2u : 0u;
+  const uint32_t stack_words = kRefWords + (T6 ? P.stack_lds * (STRIDE / 2) : P.stack_lds * STRIDE);
   lds_f32 *const lds_sum = (lds_f32 *)(smem + stack_words) + threadIdx.x;
   lds_f32 *const lds_thr = lds_sum + 3 * BLOCK;
   lds_f4 *const node_cache = (lds_f4 *)(smem + stack_words + (SUM_LDS ? kPathLdsWords * BLOCK : 0));
@@ -604,7 +609,7 @@ void trace_kernel(const KParams P) {
     S.cur = kDone; S.hit_ref = kDone; S.hit_mat = 0u;
     S.hit_n = mk(0.f, 0.f, 1.f); S.hit_prim = 0u;
     S.stk.lds = lds_stack + r * BLOCK + tid;
-    S.stk.base_at = (typename StackT::lds_u32 *)smem + r * BLOCK + tid;
+    S.stk.base_at = (typename StackT::lds_u32 *)(smem + kRefWords) + r * BLOCK + tid;
     S.stk.top_at = S.stk.base_at;
     S.stk.ovf_stride = gridDim.x * BLOCK;
     S.stk.ovf = P.ovf_stack + (size_t)blockIdx.x * BLOCK + tid;
@@ -614,7 +619,7 @@ void trace_kernel(const KParams P) {
   };
   // MODE 13: LDS address of the first stack entry of this wave's lane 0 (wave-uniform)
   const uint32_t stack_wave_at = (uint32_t)__builtin_amdgcn_readfirstlane(
-      (int)(uint32_t)(uintptr_t)((typename StackT::lds_u32 *)smem + (tid & ~63u)));
+      (int)(uint32_t)(uintptr_t)((typename StackT::lds_u32 *)(smem + kRefWords) + (tid & ~63u)));
   init_ray(ray0, 0);
   init_ray(ray1, R - 1);  // (R == 1: the same words again; ray1 is then never used)
   unsigned long long n_paths = 0, n_rays = 0, n_nodes = 0, n_tris = 0, n_sphs = 0, n_scat = 0;
@@ -637,12 +642,12 @@ void trace_kernel(const KParams P) {
   constexpr uint32_t plane = (uint32_t)(TINY ? kTinyNodes : kSmallNodes);  // nodes per plane
   typedef uint32_t u2 __attribute__((ext_vector_type(2)));
   typedef __attribute__((address_space(3))) u2 lds_u2;
-  // MODE 13: offsets of the arrays behind the node planes (16-byte units); its fourth plane holds the two child references
-  // only (8 bytes per node), the other arrays follow as in kTiny*
+  // MODE 13: offsets of the arrays behind the node planes (16-byte units): three planes (the child references are at the
+  // start of the LDS), the other arrays follow as in kTiny*
   constexpr int SPH_AT = T6 ? kTinySphAt6 : kTinySphAt, TRI_AT = SPH_AT + kTinySphs, TRIN_AT = TRI_AT + 3 * kTinyTris,
                 SPHMAT_AT = TRIN_AT + kTinyTris, TRIMAT_AT = SPHMAT_AT + 2 * kTinySphs, META_AT = TRIMAT_AT + 2 * kTinyTris;
   static_assert(!T6 || META_AT + kTinySphs / 2 == kTinyEnd6, "MODE 13: the host sizes the LDS by kTinyEnd6");
-  lds_u2 *const ref_cache = (lds_u2 *)(node_cache + 3 * plane);  // MODE 13
+  lds_u2 *const ref_cache = (lds_u2 *)smem;  // MODE 13: LDS offset 0 (the kernel has no static LDS)
   if (SMALL && !T6)
     for (uint32_t i = tid; i < n_cached * 4u; i += BLOCK) {
       float4 v = P.nodes[i];
@@ -653,8 +658,8 @@ void trace_kernel(const KParams P) {
     // the node's twelve planes regrouped per axis: (lo0.x hi0.x lo0.y hi0.y) (lo0.z hi0.z lo1.x hi1.x) (lo1.y hi1.y lo1.z hi1.z),
     // so that a slab pair needs ONE component of 1/d and of -o/d in both halves of a v_pk_fma_f32 (op_sel), and the two
     // child references in the sign-extended 16-bit form the stacks of this mode hold
-    auto tiny_ref = [](uint32_t r) {
-      return (int)r >= 0 ? r : (0xFFFF8000u | (((r >> 30) & 1u) << 14) | (((r >> 27) & 7u) << 11) | (r & 0x7FFu));
+    auto tiny_ref = [](uint32_t r) {  // (inner node: its number x 8, the byte offset of its reference pair)
+      return (int)r >= 0 ? r << 3 : (0xFFFF8000u | (((r >> 30) & 1u) << 14) | (((r >> 27) & 7u) << 11) | (r & 0x7FFu));
     };
     for (uint32_t i = tid; i < n_cached; i += BLOCK) {
       const float4 q0 = P.nodes[4u * i], q1 = P.nodes[4u * i + 1u], q2 = P.nodes[4u * i + 2u], q3 = P.nodes[4u * i + 3u];
@@ -1410,8 +1415,11 @@ void trace_kernel(const KParams P) {
               // partial cache measured no gain on the big scenes and costs a
               // test and two branches per step
               if (T6) {
-                const f4 w0 = node_cache[cur], w1 = node_cache[plane + cur], w2 = node_cache[2u * plane + cur];
-                const u2 c = ref_cache[cur];
+                // cur = node x 8: the LDS address of the reference pair as it is, and half the node's offset in a plane
+                typedef __attribute__((address_space(3))) char lds_char;
+                lds_f4 *const nd = (lds_f4 *)((lds_char *)node_cache + (cur << 1));
+                const f4 w0 = nd[0], w1 = nd[plane], w2 = nd[2u * plane];
+                const u2 c = *(lds_u2 *)(uintptr_t)cur;
                 D.q0 = make_float4(w0.x, w0.y, w0.z, w0.w);
                 D.q1 = make_float4(w1.x, w1.y, w1.z, w1.w);
                 D.q2 = make_float4(w2.x, w2.y, w2.z, w2.w);
@@ -2689,10 +2697,10 @@ int launch_frame(rtgpu_ctx *ctx, const rtgpu_camera *cam, const rtgpu_settings *
       // references (the first primitive of a leaf below 2048: kTinySphs and kTinyTris are)
       const bool tiny6 = ctx->tiny6 >= 0 ? ctx->tiny6 != 0 : kTiny6Default;
       const size_t stack_bytes6 = (size_t)stack_lds * kBlock6 * sizeof(uint16_t);
-      static_assert(kTinySphs < 2048 && kTinyTris < 2048 && kTinyNodes < 32768, "MODE 13: 16-bit references");
-      if (mode == 7 && tiny6 && stack_bytes6 + (size_t)kTinyEnd6 * 16 <= (size_t)kLdsBytes6) {
+      static_assert(kTinySphs < 2048 && kTinyTris < 2048 && kTinyNodes * 8 < 32768, "MODE 13: 16-bit references");
+      if (mode == 7 && tiny6 && (size_t)kTinyRefBytes + stack_bytes6 + (size_t)kTinyEnd6 * 16 <= (size_t)kLdsBytes6) {
         mode = 13;
-        lds_bytes = stack_bytes6 + (size_t)kTinyEnd6 * 16;
+        lds_bytes = (size_t)kTinyRefBytes + stack_bytes6 + (size_t)kTinyEnd6 * 16;
       }
     }
   }
