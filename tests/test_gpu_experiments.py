@@ -21,6 +21,9 @@ CASES = [
     ({"RTGPU_STACK_LDS": "9"}, (0, 11)),                            # nine stack entries in LDS, the rest in memory: S0's tree too
     ({"RTGPU_REFILL": "0"}, (7, 11)),                               # plain while-while traversal rounds
     ({"RTGPU_NO_MATS_CACHE": "1"}, (7, 11)),                        # trees in memory: materials through L1, not LDS
+    ({"RTGPU_TAIL_DRAW": "16"}, (7, 11)),                           # the end of the work queue in draws of 16 items for every wave
+    ({"RTGPU_TAIL_DRAW": "32"}, (7, 11)),                           # ... of 32
+    ({"RTGPU_TAIL_DRAW": "64"}, (7, 11)),                           # ... of 64, as the whole queue before round 3
 ]
 # the same over the four-wide nodes: their boxes are tighter than the slot tree's halves, so the counters of node visits and
 # triangle tests are smaller, and equal among these; frame and ids are the slot tree's
