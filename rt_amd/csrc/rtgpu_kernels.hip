@@ -756,7 +756,12 @@ void trace_kernel(const KParams P) {
     // sections (1)-(3) for one ray of the lane; true if the ray is in flight afterwards
     auto outer_sections = [&](Ray &S) __attribute__((always_inline)) {
     constexpr bool TSHARE = SHARE;
-    constexpr uint32_t kChunkMask = TSHARE ? 0xFFFFu : 0xFFFFFFFFu;
+    // MODE 13 (LEFT): the samples the item still has to trace ride in the chunk's register above its eight bits (a round has at
+    // most 64 chunks), so "item finished" is ONE compare; deriving the item's end from the chunk, as the other diet kernels do,
+    // is two scalar loads, a wait and a quarter-rate multiply - twice per outer iteration
+    constexpr bool LEFT = T6 && !SHARE;
+    constexpr uint32_t kChunkMask = TSHARE ? 0xFFFFu : LEFT ? 0xFFu : 0xFFFFFFFFu;
+    static_assert(kRoundChunks <= 256u, "LEFT: the chunk of a round in eight bits");
     // ---- (1) shade the rays whose traversal has finished (rows a6, a8) ----------
     if (S.alive && S.cur == kDone) {
       if (STATS == 2) { wave_tick(lane, w_shade); l_shade++; }
@@ -895,6 +900,7 @@ void trace_kernel(const KParams P) {
         if (SUM_LDS) { lds_sum[0] = lds_sum[0] + L.x; lds_sum[BLOCK] = lds_sum[BLOCK] + L.y; lds_sum[2 * BLOCK] = lds_sum[2 * BLOCK] + L.z; }
         else S.sum = S.sum + L;
         S.sample++;
+        if (LEFT) S.chunk -= 256u;
         S.alive = false;
       }
     }
@@ -909,7 +915,10 @@ void trace_kernel(const KParams P) {
       return e < K->spp ? e : K->spp;
     };
     if (TSHARE && queue_dry) S.chunk &= ~kPending;
-    bool need_pixel = !S.alive && !S.done && (!S.have_pixel || S.sample >= sample_end_of(S));
+    auto item_finished = [&](const Ray &S_) __attribute__((always_inline)) {
+      return LEFT ? S_.chunk < 256u : S_.sample >= sample_end_of(S_);
+    };
+    bool need_pixel = !S.alive && !S.done && (!S.have_pixel || item_finished(S));
     if (need_pixel && S.have_pixel) {
       if (S.pixel_valid) {
         KArgs K = kargs();
@@ -1040,6 +1049,7 @@ void trace_kernel(const KParams P) {
         S.pixel_valid = px < P.width && py < P.height;
         S.out_index = g_out + __umul24(wy, g_row) + wx;  // both below 2^24 (width <= 65536): v_mad_u32_u24 is full rate
         S.chunk = g_chunk;
+        if (LEFT && S.pixel_valid) S.chunk = g_chunk + ((g_sample_end - g_sample) << 8);
         S.have_pixel = true;
         S.sample = S.pixel_valid ? g_sample : g_sample_end;  // out-of-image pixel: nothing to trace
         S.sample_end = g_sample_end;
@@ -1122,7 +1132,7 @@ void trace_kernel(const KParams P) {
     SECTION_END(c_item);
     // (TSHARE: not a sample that a helper has - one compare: any of the bits above the chunk says no, and the only such bit a
     // lane with an item of its own can have besides its count of lent samples is kPending, cleared at the top of (2))
-    const bool own_next = !S.alive && !S.done && S.have_pixel && S.sample < sample_end_of(S) &&
+    const bool own_next = !S.alive && !S.done && S.have_pixel && !item_finished(S) &&
                           (!TSHARE || S.chunk <= kChunkMask);
     if (own_next || (TSHARE && queue_dry && !S.alive && (S.chunk & kFresh))) {
       if (TSHARE && queue_dry) S.chunk &= ~kFresh;
