@@ -910,9 +910,10 @@ void trace_kernel(const KParams P) {
     // last sample of the item + 1: the end of its chunk, or of the frame (an out-of-image pixel starts there)
     auto sample_end_of = [&](const Ray &S_) __attribute__((always_inline)) {
       if (!DIET) return S_.sample_end;
-      KArgs K = kargs();
-      const uint32_t e = ((S_.chunk & kChunkMask) + 1u) * K->chunk_samples;
-      return e < K->spp ? e : K->spp;
+      // (the slot-tree kernels have the two scalar registers to keep these in: asked twice per outer iteration, a load from the
+      // kernel-argument segment and its wait each time cost more than they)
+      const uint32_t e = ((S_.chunk & kChunkMask) + 1u) * P.chunk_samples;
+      return e < P.spp ? e : P.spp;
     };
     if (TSHARE && queue_dry) S.chunk &= ~kPending;
     auto item_finished = [&](const Ray &S_) __attribute__((always_inline)) {
