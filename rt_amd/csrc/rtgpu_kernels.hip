@@ -595,6 +595,7 @@ void trace_kernel(const KParams P) {
   };
   // (named objects, not an array: the compiler splits them into registers before it looks at any loop)
   Ray ray0, ray1;  // ray1: R == 2 only
+  const uint32_t stack_slot = ((lane & 31u) << 1) | (lane >> 5);  // MODE 13: the lane's place among its wave's 64 stack columns
   auto init_ray = [&](Ray &S, int r) __attribute__((always_inline)) {
     S.done = S.alive = S.have_pixel = S.pixel_valid = false;
     S.px = S.py = S.out_index = S.sample = S.sample_end = S.chunk = S.bounce = 0u;
@@ -609,7 +610,9 @@ void trace_kernel(const KParams P) {
     S.cur = kDone; S.hit_ref = kDone; S.hit_mat = 0u;
     S.hit_n = mk(0.f, 0.f, 1.f); S.hit_prim = 0u;
     S.stk.lds = lds_stack + r * BLOCK + tid;
-    S.stk.base_at = (typename StackT::lds_u32 *)(smem + kRefWords) + r * BLOCK + tid;
+    // MODE 13: 16-bit entries put two lanes into every bank; lanes l and l + 32 share a word (the LDS serves a wave's halves in
+    // turn, so those two never meet), not lanes 2k and 2k + 1 (which conflict whenever their stacks differ in depth)
+    S.stk.base_at = (typename StackT::lds_u32 *)(smem + kRefWords) + r * BLOCK + (T6 ? (tid & ~63u) + stack_slot : tid);
     S.stk.top_at = S.stk.base_at;
     S.stk.ovf_stride = gridDim.x * BLOCK;
     S.stk.ovf = P.ovf_stack + (size_t)blockIdx.x * BLOCK + tid;
@@ -1198,7 +1201,7 @@ void trace_kernel(const KParams P) {
         // this kernel has none to spare (the empty asm keeps the sum from being hoisted out of the loop)
         uint32_t wave_at = stack_wave_at;
         asm volatile("" : "+s"(wave_at));
-        S.stk.top_at = (typename StackT::lds_u32 *)(uintptr_t)(wave_at + lane * (uint32_t)sizeof(StackEntry));
+        S.stk.top_at = (typename StackT::lds_u32 *)(uintptr_t)(wave_at + (((lane & 31u) << 1) | (lane >> 5)) * (uint32_t)sizeof(StackEntry));
       } else {
         S.stk.reset();
       }
