@@ -1373,8 +1373,8 @@ void trace_kernel(const KParams P) {
             // node slot at cur << 6: origin | family, then four children x three axes of (lo | hi) halves
             const uint4 *n = (const uint4 *)(nodes_base + (cur << 6));
             bool fast = true;
-            const uint32_t top = HYBRID ? stk.peek_hybrid(fast) : stk.peek();
             const uint4 hd = n[0], pa = n[1], pb = n[2], pc = n[3];
+            const uint32_t top = HYBRID ? stk.peek_hybrid(fast) : stk.peek();
             if (STATS == 2) { l_node++; if (!fast) wave_tick(lane, w_slow); }
             if (STATS) n_nodes++;
             // t = half * (1/d) + (origin * (1/d) - o/d): the second term once per node and axis
