@@ -459,7 +459,7 @@ __device__ __forceinline__ void wave_tick(unsigned lane, unsigned long long &c) 
 // (six planes, kWideCached nodes apart) and sends deeper stack entries to global memory (the LDS
 // copy measured slower and is off unless RTGPU_WIDE_CACHE=1; the hybrid stack is what trees with a
 // stack bound above 40 entries run on).  7: as 2 for a scene that fits LDS WHOLE (kTiny* above):
-// spheres, triangles and per-primitive shading records behind the tree; S0 runs this.
+// spheres, triangles and per-primitive shading records behind the tree; S0 ran this until mode 13.
 // 8: as 7 with TWO rays per lane traversed in lock step (R = 2 below) in blocks of kBlock2 threads:
 // every lane owns two work items, each with its own traversal stack; a traversal step requests the
 // nodes (or primitives) of BOTH rays before it tests either, so that one ray's LDS round trip hides
@@ -474,6 +474,11 @@ __device__ __forceinline__ void wave_tick(unsigned lane, unsigned long long &c) 
 // 11 and 12: as 5 and 6 over the SLOT TREE (rtgpu_format.h): four-wide nodes of 64 bytes - the child boxes as binary16 offsets
 // from the node's origin, which v_fma_mix_f32 multiplies into the slab test as they are - in ONE array of 64-byte slots with
 // the primitives, the children of a node adjacent.  Four loads per node step instead of six, no record across a line.
+// 13: as 7 at SIX waves per SIMD: two blocks of kBlock6 threads per CU, each with its own copy of the scene.  What makes both
+// fit - 80 vector registers, 80 KiB of LDS per block: the node planes of the LDS copy regrouped per axis, so that v_pk_fma_f32
+// picks the component of 1/d and -o/d it needs with op_sel (six registers of slab constants instead of twelve); child
+// references and stack entries of 16 bits (sign-extended when read), the reference pairs in a table at LDS offset 0 and an
+// inner node's reference the byte offset of its pair; the work item's fields derived or packed.  S0 runs this (RTGPU_TINY6=0: 7).
 // (The slot-exchange experiment of round 2 - modes 8-10 then, profiles/r02/experiments.txt H and J -
 // was a measured negative and is gone from the source.)
 template <int STATS, int REFILL, int MODE>
